@@ -1,0 +1,254 @@
+"""Generate the golden fixtures tests/golden/*.npz by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the fixtures are data
+(inputs + the reference's outputs), committed so that the oracle and the HIP path can
+be checked anywhere. Re-run:  python tests/golden/make_golden.py
+
+Fixture names follow SURVEY.md section 8(c): F-KNN, F-E2E (incl. F-EDGE intermediates),
+F-MS (+ guard-loop case), F-FIT, F-RES, F-W.
+"""
+import os
+import sys
+import warnings
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "sed-net_amd"))
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sednet_hip import synth  # noqa: E402
+
+torch.set_num_threads(8)
+F32 = np.float32
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  [{', '.join(arrays)}]")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ----------------------------------------------------------------------------------------
+def gen_knn():
+    from src.PointNet import knn, knn_points_normals, get_graph_feature
+
+    out = {}
+    for tag, (C, N, k) in {"a": (6, 512, 20), "b": (64, 512, 20), "c": (64, 1024, 64)}.items():
+        rng = np.random.default_rng(100 + C + N + k)
+        if C == 6:
+            p, n, _, _ = synth.synthetic_cloud(7, N)
+            x = np.concatenate([p, n], 1).T[None]
+            idx = knn_points_normals(t(x), k, k, 1.0).numpy()
+        else:
+            x = rng.normal(size=(1, C, N)).astype(F32)
+            idx = knn(t(x), k, k).numpy()
+        out[f"x_{tag}"] = x.astype(F32)
+        out[f"idx_{tag}"] = idx.astype(np.int32)
+        out[f"k_{tag}"] = np.int32(k)
+    # subsampled variant k1 != k2 (PointNet.py:65) and the gathered feature tensor itself
+    x = out["x_b"]
+    out["idx_b_k1_5_k2_20"] = knn(t(x), 5, 20).numpy().astype(np.int32)
+    xs = x[:, :8, :64].copy()
+    out["feat_x"] = xs
+    out["feat_idx"] = knn(t(xs), 4, 4).numpy().astype(np.int32)
+    out["feat_out"] = get_graph_feature(t(xs), 4, 4).numpy()
+    save("f_knn", **out)
+
+
+# ----------------------------------------------------------------------------------------
+def build_ref_model(k, salt):
+    from src.SEDNet import SEDNet
+
+    m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+               combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+    sd = {k_: t(v) for k_, v in synth.closed_form_state_dict(salt).items()}
+    missing = m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m
+
+
+def gen_e2e():
+    N, k = 512, 20
+    p, n, labels, types = synth.synthetic_cloud(21, N)
+    x = np.concatenate([p, n], 1).T[None].astype(F32)
+    m = build_ref_model(k, salt=1)
+    with torch.no_grad():
+        x4, feats = m.encoder(t(x))
+        emb, logp, _, edges = m(t(x), None, False)
+    save("f_e2e", x=x, k=np.int32(k), salt=np.int32(1), x4=x4.numpy(), feats=feats.numpy(),
+         embedding=emb.numpy(), log_prob=logp.numpy(), edges=edges.numpy())
+
+
+# ----------------------------------------------------------------------------------------
+def gen_ms():
+    from src.mean_shift import MeanShift
+
+    ms = MeanShift()
+    out = {}
+    # well separated clusters, d = 128: bandwidth, iteration snapshots, nms, labels
+    X, assign = synth.clustered_embedding(N=800, d=128, n_clusters=12, sigma=0.01, seed=5)
+    Xt = t(X)
+    np.random.seed(0)
+    bw = ms.compute_bandwidth(Xt, 800, 0.05)
+    out["X"] = X
+    out["assign"] = assign.astype(np.int32)
+    out["bw_q05_ns800"] = bw.numpy()
+    bwc = torch.clamp(bw, min=0.003)
+    for it in (1, 5, 50):
+        nx, _ = ms.mean_shift_(Xt, bwc, iterations=it)
+        out[f"newX_it{it}"] = nx.numpy() if it != 5 else nx.numpy()[:64]
+    cen, ids, lab = ms.nms(nx, Xt, bwc)
+    out["nms_ids"] = ids.numpy().astype(np.int32)
+    out["nms_labels"] = lab.numpy().astype(np.int32)
+    np.random.seed(0)
+    newX, center, bw2, labels = ms.mean_shift(Xt, 800, 0.05, 50)
+    out["ms_labels"] = labels.numpy().astype(np.int32)
+    out["ms_bw"] = bw2.numpy()
+    out["ms_center"] = center.numpy()
+    # script-style call: num_samples = 10000 > N (K = int(q * 10000), rows not clamped)
+    np.random.seed(0)
+    _, _, bw3, labels3 = ms.mean_shift(Xt, 10000, 0.015, 50)
+    out["script_bw"] = bw3.numpy()
+    out["script_labels"] = labels3.numpy().astype(np.int32)
+
+    # d = 140 (HPNet-widened embedding): only bw + labels
+    X140, _ = synth.clustered_embedding(N=600, d=140, n_clusters=9, sigma=0.01, seed=6)
+    np.random.seed(0)
+    _, _, bw140, lab140 = ms.mean_shift(t(X140), 600, 0.05, 50)
+    out["X140"] = X140
+    out["bw140"] = bw140.numpy()
+    out["labels140"] = lab140.numpy().astype(np.int32)
+
+    # guard loop (generate_predictions_aug.py:25-35): 60 tight clusters in 30 close pairs ->
+    # first passes give > 49 clusters, quantile *= 1.2 until pairs merge.
+    rng = np.random.default_rng(11)
+    d = 32
+    base = rng.normal(size=(30, d)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    twin = base + 0.08 * rng.normal(size=(30, d)); twin /= np.linalg.norm(twin, axis=1, keepdims=True)
+    C = np.concatenate([base, twin])
+    a = np.repeat(np.arange(60), 20)
+    Xg = C[a] + 0.002 * rng.normal(size=(1200, d)); Xg /= np.linalg.norm(Xg, axis=1, keepdims=True)
+    Xg = Xg.astype(F32)
+    q, counts, bws = 0.008, [], []
+    np.random.seed(0)
+    while True:
+        _, center, bwg, labg = ms.mean_shift(t(Xg), 1200, q, 50)
+        counts.append(int(torch.unique(labg).shape[0])); bws.append(float(bwg))
+        if counts[-1] > 49:
+            q *= 1.2
+        else:
+            break
+    out["Xg"] = Xg
+    out["guard_q0"] = np.float64(0.008)
+    out["guard_counts"] = np.array(counts, np.int32)
+    out["guard_bws"] = np.array(bws, F32)
+    out["guard_labels"] = labg.numpy().astype(np.int32)
+    print("guard passes:", counts, bws)
+    save("f_ms", **out)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_fit():
+    from src.primitive_forward import Fit
+    from src.primitives import ComputePrimitiveDistance
+    from src.fitting_utils import weights_normalize, LeastSquares
+    from src.segment_utils import to_one_hot
+
+    fit = Fit()
+    cd = ComputePrimitiveDistance(reduce=False)
+    out = {}
+    cases = []
+
+    def add(name, kind, p, n, w):
+        p, n, w = p.astype(F32), n.astype(F32), w.astype(F32).reshape(-1, 1)
+        out[f"{name}_p"], out[f"{name}_n"], out[f"{name}_w"] = p, n, w
+        out[f"{name}_kind"] = np.int32(kind)
+        P, Nn, W = t(p), t(n), t(w)
+        if kind == synth.PLANE:
+            a, d = fit.fit_plane_torch(P, Nn, W)
+            out[f"{name}_a"], out[f"{name}_d"] = a.numpy(), d.numpy()
+            out[f"{name}_res"] = cd.distance_from_plane(P, [a.reshape(3, 1), d]).numpy()
+        elif kind == synth.SPHERE:
+            c, r = fit.fit_sphere_torch(P, Nn, W)
+            out[f"{name}_c"], out[f"{name}_r"] = c.numpy(), r.numpy()
+            out[f"{name}_res"] = cd.distance_from_sphere(P, [c, r]).numpy()
+        elif kind == synth.CYLINDER:
+            a, c, r = fit.fit_cylinder_torch(P, Nn, W)
+            out[f"{name}_a"], out[f"{name}_c"], out[f"{name}_r"] = a.numpy(), c.numpy(), r.numpy()
+            out[f"{name}_res"] = cd.distance_from_cylinder(P, [a, c, r]).numpy()
+        elif kind == synth.CONE:
+            apex, axis, th = fit.fit_cone_torch(P, Nn, W)
+            out[f"{name}_apex"], out[f"{name}_axis"], out[f"{name}_theta"] = \
+                apex.numpy().reshape(3), axis.numpy().reshape(3), th.numpy()
+            out[f"{name}_res"] = cd.distance_from_cone(P, [apex.reshape(1, 3), axis.reshape(3, 1), th]).numpy()
+        cases.append(name)
+
+    # --- the reference's own test inputs (Fitting_patches_and_edges/test_fitting_utils.py:12-13,28,47)
+    p, n = fit.sample_cone(np.array([0.0, 0.0, 0]), np.array([1, 1, 0]), np.pi / 3)
+    add("ref_cone", synth.CONE, p[::5], n[::5], np.ones(p[::5].shape[0]))
+    p, n = fit.sample_cylinder(1, np.array([0, 0, 0]), np.array([1, 2, 0]) / np.sqrt(5))
+    add("ref_cyl", synth.CYLINDER, p, n, np.ones(p.shape[0]))
+    p, n = fit.sample_sphere(1, np.array([0, 0, 0]))
+    add("ref_sph", synth.SPHERE, p[::10], n[::10], np.ones(p[::10].shape[0]))
+    # known-answer plane through 0.3*n, n = (1,2,2)/3
+    rng = np.random.default_rng(3)
+    nn = np.array([1, 2, 2]) / 3.0
+    u = np.cross(nn, [1, 0, 0]); u /= np.linalg.norm(u); v = np.cross(nn, u)
+    st = rng.uniform(-1, 1, size=(400, 2))
+    p = 0.3 * nn + st[:, :1] * u + st[:, 1:] * v
+    add("ka_plane", synth.PLANE, p, np.broadcast_to(nn, p.shape), np.ones(400))
+
+    # --- analytic patches: clean, noisy, soft-weighted
+    for i, kind in enumerate([synth.PLANE, synth.SPHERE, synth.CYLINDER, synth.CONE]):
+        rng = np.random.default_rng(40 + i)
+        p, n = synth.sample_primitive(kind, 700, rng)
+        add(f"clean{kind}", kind, p, n, np.ones(700) + np.finfo(np.float32).eps)
+        pn = p + rng.normal(scale=0.004, size=p.shape)
+        nnz = n + rng.normal(scale=0.03, size=n.shape); nnz /= np.linalg.norm(nnz, axis=1, keepdims=True)
+        add(f"noisy{kind}", kind, pn, nnz, rng.uniform(0.05, 1.0, size=700))
+
+    # --- degenerate: sphere fit on coplanar points (rank-deficient -> ridge branch, fitting_utils.py:52-64)
+    rng = np.random.default_rng(60)
+    st = rng.uniform(-0.5, 0.5, size=(300, 2))
+    p = np.concatenate([st, np.zeros((300, 1))], 1) + np.array([0.1, -0.2, 0.3])
+    add("degen_sphere_coplanar", synth.SPHERE, p, np.broadcast_to([0, 0, 1.0], p.shape), np.ones(300))
+    # --- degenerate: cone whose normals are coplanar (cond > 1e5 -> zero cone, primitive_forward.py:822-827)
+    p, n = synth.sample_primitive(synth.CYLINDER, 300, np.random.default_rng(61))
+    add("degen_cone_zero", synth.CONE, p, n, np.ones(300))
+
+    out["cases"] = np.array(cases)
+
+    # --- weights helpers
+    rng = np.random.default_rng(70)
+    wts = rng.uniform(-1, 1, size=(5, 64)).astype(F32)
+    out["wn_in"] = wts
+    out["wn_out"] = weights_normalize(t(wts), torch.tensor(0.3)).numpy()
+    out["wn_out_single"] = weights_normalize(t(wts[:1]), torch.tensor(0.3)).numpy()
+    lab = rng.integers(0, 7, size=50)
+    out["oh_in"] = lab.astype(np.int32)
+    out["oh_out"] = to_one_hot(lab, 7).numpy()
+    # lstsq on a rank-deficient and a full-rank system
+    ls = LeastSquares()
+    A = rng.normal(size=(40, 3)).astype(F32); Y = rng.normal(size=(40, 1)).astype(F32)
+    out["ls_A"], out["ls_Y"], out["ls_x"] = A, Y, ls.lstsq(t(A), t(Y)).numpy()
+    A2 = A.copy(); A2[:, 2] = A2[:, 0] * 2 - A2[:, 1]
+    out["ls_A2"], out["ls_x2"] = A2, ls.lstsq(t(A2), t(Y)).numpy()
+    save("f_fit", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit"]
+    for w in which:
+        globals()["gen_" + w]()

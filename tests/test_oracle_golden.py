@@ -1,0 +1,186 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the reference itself
+(tests/golden/make_golden.py). CPU-only: runs under `-m "not gpu"`."""
+import numpy as np
+import pytest
+
+from oracle import backbone, fit, graph, mean_shift
+from sednet_hip import synth
+
+
+def set_match_rate(a, b):
+    """fraction of rows whose neighbour SETS agree."""
+    return np.mean([set(r) == set(s) for r, s in zip(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]))])
+
+
+# ------------------------------------------------------------------------------------- F-KNN
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_knn_matches_reference(golden, tag):
+    g = golden("f_knn")
+    x, ref, k = g[f"x_{tag}"], g[f"idx_{tag}"], int(g[f"k_{tag}"])
+    got = graph.knn_points_normals(x, k, k) if x.shape[1] == 6 else graph.knn(x, k, k)
+    assert got.shape == ref.shape
+    # ordered equality except where fp32 near-ties make the order legitimately ambiguous
+    score = (graph.knn_points_normals_scores(x[0]) if x.shape[1] == 6 else graph.knn_scores(x[0]))
+    srt = -np.sort(-score, axis=-1)[:, :k + 1]
+    ambiguous = (np.abs(np.diff(srt, axis=1)) <= 1e-5 * np.maximum(1.0, np.abs(srt[:, 1:]))).any(1)
+    same = (got[0] == ref[0]).all(1)
+    assert (same | ambiguous).all()
+    assert same.mean() > 0.97
+    assert set_match_rate(got[0][~ambiguous], ref[0][~ambiguous]) == 1.0
+    assert (got[0][:, 0] == np.arange(x.shape[2])).mean() > 0.99      # self is neighbour 0
+
+
+def test_knn_subsample_and_graph_feature(golden):
+    g = golden("f_knn")
+    got = graph.knn(g["x_b"], 5, 20)
+    assert (got == g["idx_b_k1_5_k2_20"]).mean() > 0.99
+    feat = graph.get_graph_feature(g["feat_x"], 4, 4, idx=g["feat_idx"].astype(np.int64))
+    np.testing.assert_array_equal(feat, g["feat_out"])                 # pure data movement: bit exact
+
+
+# ------------------------------------------------------------------------------------- F-E2E
+def test_backbone_matches_reference(golden):
+    g = golden("f_e2e")
+    params = synth.closed_form_state_dict(int(g["salt"]))
+    x4, feats = backbone.encoder_forward(params, g["x"], int(g["k"]))
+    np.testing.assert_allclose(feats, g["feats"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(x4, g["x4"], rtol=0, atol=2e-4)
+    emb, logp, edges = backbone.sednet_forward(params, g["x"], int(g["k"]))
+    np.testing.assert_allclose(emb, g["embedding"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(logp, g["log_prob"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(edges, g["edges"], rtol=0, atol=5e-4)
+    assert (np.argmax(logp, 1) == np.argmax(g["log_prob"], 1)).mean() > 0.999
+
+
+# ------------------------------------------------------------------------------------- F-MS
+def test_bandwidth_matches_reference(golden):
+    g = golden("f_ms")
+    bw = mean_shift.compute_bandwidth(g["X"], 800, 0.05)
+    np.testing.assert_allclose(bw, g["bw_q05_ns800"], rtol=2e-5)
+
+
+def test_mean_shift_iterations_match_reference(golden):
+    g = golden("f_ms")
+    bw = max(np.float32(g["bw_q05_ns800"]), np.float32(0.003))
+    snaps = {1: None, 5: None, 50: None}
+    mean_shift.mean_shift_iterations(g["X"], bw, 50, snaps)
+    np.testing.assert_allclose(snaps[1], g["newX_it1"], atol=2e-6)
+    np.testing.assert_allclose(snaps[5][:64], g["newX_it5"], atol=5e-6)
+    np.testing.assert_allclose(snaps[50], g["newX_it50"], atol=1e-5)
+
+
+def test_nms_and_labels_match_reference(golden):
+    g = golden("f_ms")
+    bw = max(np.float32(g["bw_q05_ns800"]), np.float32(0.003))
+    _, ids, labels = mean_shift.nms(g["newX_it50"], g["X"], bw)
+    # which converged row represents a cluster depends on last-ulp noise; labels after
+    # canonicalisation are the invariant.
+    assert len(ids) == len(g["nms_ids"]) == 12
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels),
+                                  mean_shift.canonical_labels(g["nms_labels"]))
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels),
+                                  mean_shift.canonical_labels(g["assign"]))
+
+
+def test_mean_shift_end_to_end_matches_reference(golden):
+    g = golden("f_ms")
+    _, center, bw, labels = mean_shift.mean_shift(g["X"], 800, 0.05, 50)
+    np.testing.assert_allclose(bw, g["ms_bw"], rtol=2e-5)
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels), mean_shift.canonical_labels(g["ms_labels"]))
+    _, _, bw, labels = mean_shift.mean_shift(g["X"], 10000, 0.015, 50)      # script-style num_samples > N
+    np.testing.assert_allclose(bw, g["script_bw"], rtol=2e-5)
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels),
+                                  mean_shift.canonical_labels(g["script_labels"]))
+    _, _, bw, labels = mean_shift.mean_shift(g["X140"], 600, 0.05, 50)      # d = 140
+    np.testing.assert_allclose(bw, g["bw140"], rtol=2e-5)
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels), mean_shift.canonical_labels(g["labels140"]))
+
+
+def test_guard_loop_matches_reference(golden):
+    g = golden("f_ms")
+    center, bw, labels, passes = mean_shift.guard_mean_shift(g["Xg"], float(g["guard_q0"]), 50, num_samples=1200)
+    assert passes == len(g["guard_counts"])
+    np.testing.assert_allclose(bw, g["guard_bws"][-1], rtol=1e-4)
+    assert np.unique(labels).shape[0] == g["guard_counts"][-1]
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels), mean_shift.canonical_labels(g["guard_labels"]))
+
+
+# ------------------------------------------------------------------------------------- F-FIT / F-RES
+def _axis_close(a, b, tol):
+    a, b = np.ravel(a), np.ravel(b)
+    return min(np.abs(a - b).max(), np.abs(a + b).max()) < tol
+
+
+def _cases(g):
+    return [str(c) for c in g["cases"]]
+
+
+def test_fits_match_reference(golden):
+    g = golden("f_fit")
+    for name in _cases(g):
+        kind = int(g[f"{name}_kind"])
+        p, n, w = g[f"{name}_p"], g[f"{name}_n"], g[f"{name}_w"]
+        tol = 2e-3 if name.startswith(("degen", "ref_cone")) else 2e-4
+        if kind == synth.PLANE:
+            a, d = fit.fit_plane(p, w)
+            assert _axis_close(a, g[f"{name}_a"], tol), name
+            assert abs(abs(d) - abs(g[f"{name}_d"])) < tol, name
+        elif kind == synth.SPHERE:
+            c, r = fit.fit_sphere(p, w)
+            np.testing.assert_allclose(c, g[f"{name}_c"], atol=tol, err_msg=name)
+            np.testing.assert_allclose(r, g[f"{name}_r"], atol=tol, err_msg=name)
+        elif kind == synth.CYLINDER:
+            a, c, r = fit.fit_cylinder(p, n, w)
+            assert _axis_close(a, g[f"{name}_a"], tol), name
+            # The projected circle fit is rank-2, so the reference always lands in its ridge branch
+            # (fitting_utils.py:52-64, lambda=1e-4): the centre's along-axis component is amplified fp32
+            # noise (O(1e-2), LAPACK-specific) and leaks into r via r^2 = r_perp^2 + c_axis^2.
+            # The well-defined quantities are the perpendicular centre and r_perp.
+            ax = np.ravel(g[f"{name}_a"])
+            perp = lambda v: np.ravel(v) - np.dot(np.ravel(v), ax) * ax
+            rperp = lambda c_, r_: np.sqrt(r_ ** 2 - np.dot(np.ravel(c_), ax) ** 2)
+            ctol = 2e-3 if name.startswith("noisy") else 5 * tol
+            np.testing.assert_allclose(perp(c), perp(g[f"{name}_c"]), atol=ctol, err_msg=name)
+            np.testing.assert_allclose(rperp(c, r), rperp(g[f"{name}_c"], g[f"{name}_r"]), atol=ctol, err_msg=name)
+        else:
+            apex, axis, th = fit.fit_cone(p, n, w)
+            np.testing.assert_allclose(np.ravel(apex), g[f"{name}_apex"], atol=5 * tol, err_msg=name)
+            np.testing.assert_allclose(np.ravel(axis), g[f"{name}_axis"], atol=tol, err_msg=name)
+            np.testing.assert_allclose(th, g[f"{name}_theta"], atol=tol, err_msg=name)
+
+
+def test_known_answers(golden):
+    """SURVEY.md section 8(c) known answers (analytic truth, independent of the captured digits)."""
+    g = golden("f_fit")
+    a, d = fit.fit_plane(g["ka_plane_p"], g["ka_plane_w"])
+    assert _axis_close(a, np.array([1, 2, 2]) / 3.0, 1e-5) and abs(abs(d) - 0.3) < 1e-5
+    a, c, r = fit.fit_cylinder(g["ref_cyl_p"], g["ref_cyl_n"], g["ref_cyl_w"])
+    assert _axis_close(a, np.array([1, 2, 0]) / np.sqrt(5), 1e-4) and abs(r - 1.0) < 1e-3
+    apex, axis, th = fit.fit_cone(g["degen_cone_zero_p"], g["degen_cone_zero_n"], g["degen_cone_zero_w"])
+    assert np.all(apex == 0) and np.all(np.ravel(axis) == [1, 0, 0]) and th == 0
+
+
+def test_residuals_match_reference(golden):
+    g = golden("f_fit")
+    for name in _cases(g):
+        kind = int(g[f"{name}_kind"])
+        p = g[f"{name}_p"]
+        if kind == synth.PLANE:
+            r = fit.distance_from_plane(p, g[f"{name}_a"], g[f"{name}_d"])
+        elif kind == synth.SPHERE:
+            r = fit.distance_from_sphere(p, g[f"{name}_c"], g[f"{name}_r"])
+        elif kind == synth.CYLINDER:
+            r = fit.distance_from_cylinder(p, g[f"{name}_a"], g[f"{name}_c"], g[f"{name}_r"])
+        else:
+            r = fit.distance_from_cone(p, g[f"{name}_apex"], g[f"{name}_axis"], g[f"{name}_theta"])
+        np.testing.assert_allclose(r, g[f"{name}_res"], rtol=2e-4, atol=1e-7, err_msg=name)
+
+
+def test_weight_helpers_and_lstsq(golden):
+    g = golden("f_fit")
+    np.testing.assert_allclose(fit.weights_normalize(g["wn_in"], 0.3), g["wn_out"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(fit.weights_normalize(g["wn_in"][:1], 0.3), g["wn_out_single"], rtol=1e-5)
+    np.testing.assert_array_equal(fit.to_one_hot(g["oh_in"], 7), g["oh_out"])
+    np.testing.assert_allclose(fit.lstsq(g["ls_A"], g["ls_Y"]), g["ls_x"], rtol=1e-4, atol=1e-6)
+    # rank-deficient -> ridge branch with lambda=1e-6..1e-4 in fp32: ill-conditioned by construction
+    np.testing.assert_allclose(fit.lstsq(g["ls_A2"], g["ls_Y"]), g["ls_x2"], rtol=5e-3, atol=1e-3)

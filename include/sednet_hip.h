@@ -1,0 +1,70 @@
+/* sednet_hip.h -- C ABI of libsedhip.so: the MI355X (gfx950) kernels behind SED-Net's inference hot path.
+ *
+ * The reference (yuanqili78/SED-Net) has no FFI on this path: it is reached through a Python operator
+ * surface (src/SEDNet.py, src/PointNet.py, src/mean_shift.py, src/primitive_forward.py, src/primitives.py)
+ * built from stock torch ops. This header is what a maintainer binds (ctypes) to replace
+ * those ops; each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host"; the caller owns every buffer;
+ *     the library allocates nothing and keeps no global state (re-entrant).
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is enqueued on it,
+ *     nothing synchronises.
+ *   - return value: 0 = success, SED_EINVAL (-1) bad argument, SED_EUNSUPPORTED (-2) size outside the
+ *     instantiated range, otherwise a hipError_t. Never exits, never prints
+ *     (the reference's CUDA helpers printf or exit(-1): chamfer_distance.cu:152-154, cuda_utils.h:35-44).
+ *   - point-major layout: per-point feature rows are contiguous, [B, N, D] fp32 with D a multiple of 32
+ *     (zero padded) and at most 160; indices are int32.
+ */
+#ifndef SEDNET_HIP_H
+#define SEDNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sed_stream_t; /* == hipStream_t */
+
+#define SED_OK 0
+#define SED_EINVAL (-1)
+#define SED_EUNSUPPORTED (-2)
+
+/* ---- build / identity -------------------------------------------------------------------------------- */
+int sed_abi_version(void);           /* bumped on any signature change */
+const char* sed_build_arch(void);    /* "gfx950" */
+
+/* ---- pairwise rows + exact row selection (kNN graph, bandwidth) ---------------------------------------
+ * D [B,N,ldD] workspace rows, consumed once by the selection calls. */
+
+/* D[i][j] = 2 - 2 x_i.x_j                                   src/mean_shift.py:130 */
+int sed_pairdist_ms_f32(int B, int N, int d, const float* X, float* D, int ldD, sed_stream_t stream);
+/* D[i][j] = -(((-xx_j) + 2 x_i.x_j) - xx_i); first C of d channels are real.   src/PointNet.py:76-78 (knn) */
+int sed_pairdist_knn_f32(int B, int N, int d, int C, const float* X, float* xx_ws /*[B*N]*/, float* D, int ldD,
+                         sed_stream_t stream);
+/* D[i][j] = Dp (1 + W Dn) on x6 [B,6,N] channel-major (xyz, unit normal).     src/PointNet.py:107-128 */
+int sed_pairdist_pn_f32(int B, int N, float W, const float* x6, float* D, int ldD, sed_stream_t stream);
+/* k-th smallest per row -> kth [B,N]                         src/mean_shift.py:133-135 */
+int sed_row_kth_f32(int B, int N, int ldD, int k, const float* D, float* kth, sed_stream_t stream);
+/* indices of the k smallest per row, ascending by (value, index) -> idx [B,N,k]   src/PointNet.py:83,133 (topk) */
+int sed_row_topk_idx_f32(int B, int N, int ldD, int k, const float* D, int* idx, sed_stream_t stream);
+
+/* ---- mean-shift clustering --------------------------------------------------------------------------- */
+/* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */
+int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, float* bw, sed_stream_t stream);
+/* `iters` gaussian mean-shift iterations on unit rows, X [B,N,d] -> newX [B,N,d]; bw [B] on device.
+ * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
+int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                       sed_stream_t stream);
+/* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
+ * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
+ * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */
+size_t sed_ms_nms_workspace_bytes(int B, int N);
+int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, const float* bw, int* labels,
+                   int* centre_ids, int* n_centres, int* n_labels, void* ws, size_t ws_bytes, sed_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEDNET_HIP_H */

@@ -1,0 +1,45 @@
+// Shared helpers for the SED-Net gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SED_OK 0
+#define SED_EINVAL (-1)      // bad argument (null pointer, unsupported size, workspace too small)
+#define SED_EUNSUPPORTED (-2)
+
+#define SED_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// C/D row of accumulator register r for v_mfma_f32_32x32x2_f32 (lane>>5 = hi):
+//   row = (r & 3) + 8 * (r >> 2) + 4 * hi ; col = lane & 31
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// float -> uint32 whose unsigned order equals the float order (-0 < +0, NaNs at the ends)
+__device__ __forceinline__ uint32_t f32_sortable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sortable_f32(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+static inline int sed_pad_dim(int d) {      // feature width the MFMA kernels are instantiated for
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 96) return 96;
+    if (d <= 128) return 128;
+    if (d <= 160) return 160;
+    return -1;
+}

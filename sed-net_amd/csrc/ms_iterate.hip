@@ -1,0 +1,187 @@
+// Mean-shift iterations on the unit hypersphere, all `iters` iterations in ONE launch.
+//
+// Replaces the loop body of /root/reference/src/mean_shift.py:56-77
+//     dist = 2 - 2 new_X X^T ; K = exp(clamp(-dist / b^2 / 2, -75, 75)) ; D = 1 / sum_j K
+//     new_X = new_X + ((K X) * D - new_X) ; new_X /= ||new_X||
+// without ever materialising the N x N matrices: flash-attention shaped, keys == values == X.
+//
+// Structure (gfx950, wave64, fp32-input MFMA v_mfma_f32_32x32x2_f32 = exact fp32 fma chains):
+//   * rows never interact across iterations (new_X[i] at t+1 depends on new_X[i] at t and the
+//     FIXED X), so one workgroup owns 128 query rows (4 waves x 32) for all iterations; no grid sync.
+//   * per 32-key tile a wave computes  S^T = X_tile . Q^T  (keys on accumulator rows, queries on
+//     lanes), P = exp(...) in registers, then  O^T += X_tile^T . P^T.  With that operand order the
+//     accumulator layout of O^T *is* the B-operand layout of Q for the next iteration's S^T, and the
+//     P registers *are* the B operand of the second product: no transposes, no LDS round trips.
+//       lane = (query = lane & 31, hi = lane >> 5); register (t, r) of Q / O holds feature
+//       d = 32 t + (r & 3) + 8 (r >> 2) + 4 hi.
+//   * X tiles (32 keys x D floats, row stride D + 4 floats -> conflict-free ds_read_b128) are staged
+//     through a double-buffered LDS ring shared by the 4 waves, one barrier per tile; X (N*D*4 B =
+//     5 MB at N = 10k, D = 128) is re-streamed from L2 / Infinity Cache every iteration.
+// Algorithmic work: 4 N^2 D flops per iteration per cloud; bound: fp32 MFMA.
+#include "common.h"
+
+namespace {
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restrict__ X,
+                                                            float* __restrict__ newX,
+                                                            const float* __restrict__ bw, int N, int iters) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;   // float4 per row
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float b2 = b * b;
+    const int ntiles = (N + 31) >> 5;
+
+    // Q fragment: q[t][4g + c] = X[qrow][32 t + 8 g + 4 hi + c]
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+
+    // staging assignment: NT float4 per thread per tile
+    f32x4 stage[NT];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+
+    for (int it = 0; it < iters; ++it) {
+        f32x16 o[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        float rsum = 0.f;
+
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const bool last = (it == iters - 1) && (tile == ntiles - 1);
+            if (!last) stage_load(tile + 1 == ntiles ? 0 : tile + 1);
+
+            const float* xt = lds[cur];
+            // ---- S^T = X_tile . Q^T  (keys on rows, queries on lanes)
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);
+                }
+            // ---- P = exp(clamp(-(2 - 2 s) / b^2 / 2))   (mean_shift.py:60-63, guard.py:7-9)
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dist = 2.0f - 2.0f * s[r];
+                float a = (-dist / b2) * 0.5f;
+                a = fminf(fmaxf(a, -75.0f), 75.0f);
+                p[r] = expf(a);
+            }
+            if (tile == ntiles - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (tile * 32 + mfma_row(r, hi) >= N) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rsum += p[r];
+            // ---- O^T += X_tile^T . P^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* xr = xt + mfma_row(r, hi) * LDX + li;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t] = mfma32(xr[32 * t], p[r], o[t]);
+            }
+
+            if (!last) stage_store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = 1.0f / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = o[t][r] * Dinv - q[t][r];
+                const float nq = q[t][r] + m;
+                q[t][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[t][r] = q[t][r] / nrm;
+    }
+
+    if (qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * D;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {q[t][4 * g], q[t][4 * g + 1], q[t][4 * g + 2], q[t][4 * g + 3]};
+                *(f32x4*)(out + 32 * t + 8 * g + 4 * hi) = v;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                                  hipStream_t stream) {
+    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX) return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
+    dim3 grid((N + 127) / 128, B), block(256);
+    switch (d / 32) {
+        case 1: ms_iterate_kernel<1><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+        case 2: ms_iterate_kernel<2><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+        case 3: ms_iterate_kernel<3><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+        case 4: ms_iterate_kernel<4><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+        case 5: ms_iterate_kernel<5><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+    }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

@@ -1,0 +1,292 @@
+// Mean-shift non-maximum suppression + label assignment, entirely on device.
+// Replaces /root/reference/src/mean_shift.py:139-179 (MeanShift.nms), which materialises three N x N
+// products and round-trips through numpy (np.unique) on the host:
+//   1. membership[p]  = argmin_i (2 - 2 c_i . x_p)          (first minimum)          :146-149
+//   2. counts[i]      = #points whose nearest centre is i ; uniques = {i : counts[i] > 0}   :152-161
+//   3. for u in uniques: vote[u] = argmax_j [ (2 - 2 c_u . c_j) < b ] * counts[j]  (first maximum) :164-171
+//      (only j in uniques can score > 0, and u itself always scores >= 1, so the U x U block suffices)
+//   4. centre ids     = sorted unique votes                                            :171
+//   5. labels[p]      = argmax_c (c_sel[c] . x_p)            (first maximum)          :177-178
+// plus the number of distinct labels used, which the caller's guard loop needs
+// (generate_predictions_aug.py:31).
+#include "common.h"
+
+namespace {
+
+// ---- 1. membership: streaming argmin over all centres, MFMA products as in ms_iterate.hip --------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restrict__ C,   // centres [B,N,D]
+                                                            const float* __restrict__ X,   // points  [B,N,D]
+                                                            int* __restrict__ member, int N) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Cc = C + (size_t)cloud * N * D;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int prow = blockIdx.x * 128 + wave * 32 + li;
+    const int prow_c = prow < N ? prow : N - 1;
+    const int ntiles = (N + 31) >> 5;
+
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Xc + (size_t)prow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    f32x4 stage[NT];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Cc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    float best = 3.0e38f;
+    int besti = 0x7fffffff;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) stage_load(tile + 1);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);   // centres on rows, points on lanes
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = tile * 32 + mfma_row(r, hi);
+            const float dist = 2.0f - 2.0f * s[r];
+            if (ci < N && (dist < best || (dist == best && ci < besti))) { best = dist; besti = ci; }
+        }
+        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float ob = xor32(best);
+    const int oi = __shfl_xor(besti, 32, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    if (prow < N && hi == 0) member[(size_t)cloud * N + prow] = besti;
+}
+
+// ---- 2. histogram -----------------------------------------------------------------------------------
+__global__ void count_members_kernel(const int* __restrict__ member, int* __restrict__ counts, int N) {
+    const int cloud = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < N) atomicAdd(&counts[(size_t)cloud * N + member[(size_t)cloud * N + p]], 1);
+}
+
+// ---- ordered compaction of {i : flag[i] > 0}, one workgroup per cloud --------------------------------
+__global__ __launch_bounds__(256) void compact_kernel(const int* __restrict__ flag, int N, int* __restrict__ list,
+                                                      int* __restrict__ count) {
+    __shared__ int wsum[4];
+    __shared__ int base;
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* f = flag + (size_t)cloud * N;
+    int* out = list + (size_t)cloud * N;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 256) {
+        const int i = i0 + tid;
+        const bool on = i < N && f[i] > 0;
+        const unsigned long long m = __ballot(on);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (on) out[off + before] = i;
+        __syncthreads();
+        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[cloud] = base;
+}
+
+// ---- 3. neighbour vote over the U x U block; one wave per unique centre --------------------------------
+__global__ __launch_bounds__(64) void centre_vote_kernel(const float* __restrict__ C, const int* __restrict__ uniq,
+                                                         const int* __restrict__ n_uniq,
+                                                         const int* __restrict__ counts, const float* __restrict__ bw,
+                                                         int N, int D, int* __restrict__ voted) {
+    extern __shared__ float cu[];
+    const int cloud = blockIdx.y;
+    const int U = n_uniq[cloud];
+    if ((int)blockIdx.x >= U) return;
+    const int lane = threadIdx.x;
+    const int* uq = uniq + (size_t)cloud * N;
+    const float* Cc = C + (size_t)cloud * N * D;
+    const int u = uq[blockIdx.x];
+    for (int c = lane; c < D; c += 64) cu[c] = Cc[(size_t)u * D + c];
+    __syncthreads();
+    const float b = bw[cloud];
+    int best_score = -1, best_j = 0x7fffffff;
+    for (int jj = lane; jj < U; jj += 64) {
+        const int j = uq[jj];
+        const float* cj = Cc + (size_t)j * D;
+        float dot = 0.f;
+        for (int c = 0; c < D; c += 4) {
+            const f32x4 v = *(const f32x4*)(cj + c);
+            dot = fmaf(cu[c], v[0], dot);
+            dot = fmaf(cu[c + 1], v[1], dot);
+            dot = fmaf(cu[c + 2], v[2], dot);
+            dot = fmaf(cu[c + 3], v[3], dot);
+        }
+        const float dist = 2.0f - 2.0f * dot;
+        const int score = dist < b ? counts[(size_t)cloud * N + j] : 0;     // mean_shift.py:168 (b, not b^2)
+        if (score > best_score) { best_score = score; best_j = j; }          // j ascending per lane
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int os = __shfl_xor(best_score, off, 64);
+        const int oj = __shfl_xor(best_j, off, 64);
+        if (os > best_score || (os == best_score && oj < best_j)) { best_score = os; best_j = oj; }
+    }
+    // a row whose every neighbour scores 0 would argmax to column 0 in the reference; cannot happen while
+    // dist(u,u) < b, kept for fidelity:
+    if (best_score <= 0) best_j = 0;
+    if (lane == 0) voted[(size_t)cloud * N + best_j] = 1;
+}
+
+// ---- 5. labels: argmax over the selected centres; one thread per point ---------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void label_kernel(const float* __restrict__ C, const float* __restrict__ X,
+                                                    const int* __restrict__ centre_ids,
+                                                    const int* __restrict__ n_centres, int N,
+                                                    int* __restrict__ labels, int* __restrict__ used) {
+    constexpr int D = 32 * NT;
+    constexpr int CH = 32;                       // centres per LDS chunk
+    __shared__ __attribute__((aligned(16))) float cs[CH * D];
+    const int cloud = blockIdx.y;
+    const int m = n_centres[cloud];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int pc = p < N ? p : N - 1;
+    const float* Cc = C + (size_t)cloud * N * D;
+    const int* ids = centre_ids + (size_t)cloud * N;
+    float x[D];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 v = *(const f32x4*)(X + ((size_t)cloud * N + pc) * D + c);
+        x[c] = v[0]; x[c + 1] = v[1]; x[c + 2] = v[2]; x[c + 3] = v[3];
+    }
+    float best = -3.0e38f;
+    int bi = 0;
+    for (int c0 = 0; c0 < m; c0 += CH) {
+        const int nc = min(CH, m - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc * (D / 4); i += 256) {
+            const int cc = i / (D / 4), c4 = i % (D / 4);
+            *(f32x4*)(&cs[cc * D + 4 * c4]) = *(const f32x4*)(Cc + (size_t)ids[c0 + cc] * D + 4 * c4);
+        }
+        __syncthreads();
+        for (int cc = 0; cc < nc; ++cc) {
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) dot = fmaf(cs[cc * D + c], x[c], dot);
+            if (dot > best) { best = dot; bi = c0 + cc; }
+        }
+    }
+    if (p < N) {
+        labels[(size_t)cloud * N + p] = bi;
+        used[(size_t)cloud * N + bi] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void count_flags_kernel(const int* __restrict__ flag, int N, int* __restrict__ count) {
+    __shared__ int part[256];
+    const int* f = flag + (size_t)blockIdx.x * N;
+    int acc = 0;
+    for (int i = threadIdx.x; i < N; i += 256) acc += f[i] > 0;
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[blockIdx.x] = part[0];
+}
+
+}  // namespace
+
+extern "C" size_t sed_ms_nms_workspace_bytes(int B, int N) {
+    // member, counts, uniq, voted, used : 5 int arrays [B,N] ; n_uniq [B]
+    return (size_t)B * N * 5 * sizeof(int) + (size_t)B * sizeof(int);
+}
+
+// centres = converged new_X [B,N,d]; X [B,N,d]; bw [B]. Outputs: labels [B,N] int32 (0..m-1, ordered by
+// centre index), centre_ids [B,N] int32 (first n_centres[b] valid, ascending), n_centres [B],
+// n_labels [B] (= number of distinct labels actually used).
+extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, const float* bw,
+                              int* labels, int* centre_ids, int* n_centres, int* n_labels, void* ws,
+                              size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !centres || !X || !bw || !labels || !centre_ids || !n_centres || !n_labels || !ws)
+        return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
+    if (ws_bytes < sed_ms_nms_workspace_bytes(B, N)) return SED_EINVAL;
+    const size_t bn = (size_t)B * N;
+    int* member = (int*)ws;
+    int* counts = member + bn;
+    int* uniq = counts + bn;
+    int* voted = uniq + bn;
+    int* used = voted + bn;
+    int* n_uniq = used + bn;
+    hipError_t e = hipMemsetAsync(counts, 0, bn * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(voted, 0, 2 * bn * sizeof(int), stream);      // voted + used
+    if (e != hipSuccess) return (int)e;
+
+    dim3 g1((N + 127) / 128, B);
+    switch (d / 32) {
+        case 1: membership_kernel<1><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+        case 2: membership_kernel<2><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+        case 3: membership_kernel<3><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+        case 4: membership_kernel<4><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+        case 5: membership_kernel<5><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+    }
+    SED_LAUNCH_CHECK();
+    count_members_kernel<<<dim3((N + 255) / 256, B), 256, 0, stream>>>(member, counts, N);
+    SED_LAUNCH_CHECK();
+    compact_kernel<<<B, 256, 0, stream>>>(counts, N, uniq, n_uniq);
+    SED_LAUNCH_CHECK();
+    centre_vote_kernel<<<dim3(N, B), 64, d * sizeof(float), stream>>>(centres, uniq, n_uniq, counts, bw, N, d, voted);
+    SED_LAUNCH_CHECK();
+    compact_kernel<<<B, 256, 0, stream>>>(voted, N, centre_ids, n_centres);
+    SED_LAUNCH_CHECK();
+    dim3 g5((N + 255) / 256, B);
+    switch (d / 32) {
+        case 1: label_kernel<1><<<g5, 256, 0, stream>>>(centres, X, centre_ids, n_centres, N, labels, used); break;
+        case 2: label_kernel<2><<<g5, 256, 0, stream>>>(centres, X, centre_ids, n_centres, N, labels, used); break;
+        case 3: label_kernel<3><<<g5, 256, 0, stream>>>(centres, X, centre_ids, n_centres, N, labels, used); break;
+        case 4: label_kernel<4><<<g5, 256, 0, stream>>>(centres, X, centre_ids, n_centres, N, labels, used); break;
+        case 5: label_kernel<5><<<g5, 256, 0, stream>>>(centres, X, centre_ids, n_centres, N, labels, used); break;
+    }
+    SED_LAUNCH_CHECK();
+    count_flags_kernel<<<B, 256, 0, stream>>>(used, N, n_labels);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

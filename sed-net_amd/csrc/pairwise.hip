@@ -1,0 +1,212 @@
+// Dense pairwise "distance" rows for the selection stages (kNN graph, mean-shift bandwidth).
+//
+//   MODE_MS  : D[i][j] = 2 - 2 x_i.x_j                       (mean_shift.py:130, compute_bandwidth)
+//   MODE_KNN : D[i][j] = -(((-xx_j) + 2 x_i.x_j) - xx_i)     (PointNet.py:76-78, knn; D = -score so that
+//              "k largest score" == "k smallest D"; the fp32 evaluation order of the reference is kept)
+//   pn kernel: D[i][j] = Dp * (1 + W * Dn)                   (PointNet.py:107-128, knn_points_normals)
+//
+// The rows are written to a caller-provided workspace and consumed once by select.hip. Products run
+// on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains); 4 waves x 32 query rows per workgroup, key tiles
+// of 32 rows staged through LDS exactly like ms_iterate.hip. Output stores are 128-byte coalesced
+// (lanes = consecutive keys). This is the round-1 form: HBM-bound on 2 * N^2 * 4 bytes per cloud
+// (write here, read in select); a fused streaming top-k that never materialises D is the planned
+// replacement.
+#include "common.h"
+
+namespace {
+
+enum { MODE_MS = 0, MODE_KNN = 1 };
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restrict__ X,
+                                                           const float* __restrict__ xx,
+                                                           float* __restrict__ Dout, int N, int ldD) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const float* xxc = xx ? xx + (size_t)cloud * N : nullptr;
+    float* Dc = Dout + (size_t)cloud * N * ldD;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int ntiles = (N + 31) >> 5;
+
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    float xq[16];
+    if (MODE == MODE_KNN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = q0 + mfma_row(r, hi);
+            xq[r] = xxc[row < N ? row : N - 1];
+        }
+    }
+
+    f32x4 stage[NT];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) stage_load(tile + 1);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        // S = Q . X_tile^T : queries on accumulator rows, keys on lanes (coalesced stores)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(q[t][4 * g + c], xa[c], s);
+            }
+        const int key = tile * 32 + li;
+        if (key < N) {
+            float xk = 0.f;
+            if (MODE == MODE_KNN) xk = xxc[key];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = q0 + mfma_row(r, hi);
+                if (row < N) {
+                    float dv;
+                    if (MODE == MODE_MS) {
+                        dv = 2.0f - 2.0f * s[r];
+                    } else {
+                        const float t1 = __fadd_rn(-xk, 2.0f * s[r]);   // (-xx_j) - inner,  inner = -2 dot
+                        dv = -__fsub_rn(t1, xq[r]);                     //  ... - xx_i ; D = -score
+                    }
+                    Dc[(size_t)row * ldD + key] = dv;
+                }
+            }
+        }
+        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// per-row squared norm, sequential over channels, products rounded before the adds
+// (PointNet.py:77  xx = torch.sum(x ** 2, dim=1))
+__global__ void row_sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows, int D, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float* x = X + (size_t)i * D;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(x[c], x[c]));
+    xx[i] = acc;
+}
+
+// first-layer metric on xyz + normals, channel-major input x6 [B,6,N]
+__global__ __launch_bounds__(256) void pair_dist_pn_kernel(const float* __restrict__ x6, float* __restrict__ Dout,
+                                                           int N, int ldD, float W) {
+    constexpr int ROWS = 32;
+    __shared__ float qs[ROWS][8];
+    const int cloud = blockIdx.z;
+    const float* xc = x6 + (size_t)cloud * 6 * N;
+    float* Dc = Dout + (size_t)cloud * N * ldD;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * ROWS;
+    if (threadIdx.x < ROWS) {
+        int i = i0 + threadIdx.x;
+        if (i >= N) i = N - 1;
+        float p0 = xc[i], p1 = xc[N + i], p2 = xc[2 * N + i];
+        qs[threadIdx.x][0] = p0; qs[threadIdx.x][1] = p1; qs[threadIdx.x][2] = p2;
+        qs[threadIdx.x][3] = xc[3 * N + i]; qs[threadIdx.x][4] = xc[4 * N + i]; qs[threadIdx.x][5] = xc[5 * N + i];
+        qs[threadIdx.x][6] = __fadd_rn(__fadd_rn(__fmul_rn(p0, p0), __fmul_rn(p1, p1)), __fmul_rn(p2, p2));
+    }
+    __syncthreads();
+    if (j >= N) return;
+    const float p0 = xc[j], p1 = xc[N + j], p2 = xc[2 * N + j];
+    const float n0 = xc[3 * N + j], n1 = xc[4 * N + j], n2 = xc[5 * N + j];
+    const float xxj = __fadd_rn(__fadd_rn(__fmul_rn(p0, p0), __fmul_rn(p1, p1)), __fmul_rn(p2, p2));
+#pragma unroll 4
+    for (int r = 0; r < ROWS; ++r) {
+        const int i = i0 + r;
+        if (i >= N) break;
+        const float dotp = fmaf(qs[r][2], p2, fmaf(qs[r][1], p1, __fmul_rn(qs[r][0], p0)));
+        const float dotn = fmaf(qs[r][5], n2, fmaf(qs[r][4], n1, __fmul_rn(qs[r][3], n0)));
+        const float dp = __fadd_rn(__fsub_rn(xxj, 2.0f * dotp), qs[r][6]);   // (xx_j - inner) + xx_i
+        const float dn = __fsub_rn(2.0f, 2.0f * dotn);
+        const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));
+        Dc[(size_t)i * ldD + j] = dv;
+    }
+}
+
+template <int MODE>
+int launch_pair(int B, int N, int d, const float* X, const float* xx, float* D, int ldD, hipStream_t stream) {
+    dim3 grid((N + 127) / 128, B), block(256);
+    switch (d / 32) {
+        case 1: pair_dist_kernel<1, MODE><<<grid, block, 0, stream>>>(X, xx, D, N, ldD); break;
+        case 2: pair_dist_kernel<2, MODE><<<grid, block, 0, stream>>>(X, xx, D, N, ldD); break;
+        case 3: pair_dist_kernel<3, MODE><<<grid, block, 0, stream>>>(X, xx, D, N, ldD); break;
+        case 4: pair_dist_kernel<4, MODE><<<grid, block, 0, stream>>>(X, xx, D, N, ldD); break;
+        case 5: pair_dist_kernel<5, MODE><<<grid, block, 0, stream>>>(X, xx, D, N, ldD); break;
+        default: return SED_EUNSUPPORTED;
+    }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+}  // namespace
+
+extern "C" int sed_pairdist_ms_f32(int B, int N, int d, const float* X, float* D, int ldD, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !X || !D || ldD < N) return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
+    return launch_pair<MODE_MS>(B, N, d, X, nullptr, D, ldD, stream);
+}
+
+// X [B,N,d] point-major, zero padded beyond the C real channels; xx_ws [B*N] floats scratch
+extern "C" int sed_pairdist_knn_f32(int B, int N, int d, int C, const float* X, float* xx_ws, float* D, int ldD,
+                                    hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !X || !D || !xx_ws || ldD < N || C > d) return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
+    const int rows = B * N;
+    row_sqnorm_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(X, xx_ws, rows, d, C);
+    SED_LAUNCH_CHECK();
+    return launch_pair<MODE_KNN>(B, N, d, X, xx_ws, D, ldD, stream);
+}
+
+// x6 [B,6,N] channel-major (xyz, normal)
+extern "C" int sed_pairdist_pn_f32(int B, int N, float W, const float* x6, float* D, int ldD, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !x6 || !D || ldD < N) return SED_EINVAL;
+    dim3 grid((N + 255) / 256, (N + 31) / 32, B);
+    pair_dist_pn_kernel<<<grid, 256, 0, stream>>>(x6, D, N, ldD, W);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

@@ -1,0 +1,70 @@
+"""ctypes binding of libsedhip.so (include/sednet_hip.h).
+
+The library is the product: there is no CPU fallback. Importing this module without a built
+libsedhip.so raises immediately, and every call raises RuntimeError on a non-zero status.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- FIRST: libsedhip.so must bind to the HIP runtime torch already loaded
+              # (torch ships its own libamdhip64; loading /opt/rocm's copy first gives two runtimes
+              # and every launch on a torch stream then fails with hipErrorNoDevice)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsedhip.so")
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+P = c_void_p  # every device pointer / stream travels as void*
+
+# name -> (restype, argtypes); mirrors include/sednet_hip.h one to one
+SIGNATURES = {
+    "sed_abi_version": (c_int, []),
+    "sed_build_arch": (ctypes.c_char_p, []),
+    "sed_pairdist_ms_f32": (c_int, [c_int, c_int, c_int, P, P, c_int, P]),
+    "sed_pairdist_knn_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "sed_pairdist_pn_f32": (c_int, [c_int, c_int, c_float, P, P, c_int, P]),
+    "sed_row_kth_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P]),
+    "sed_row_topk_idx_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P]),
+    "sed_ms_bandwidth_finalize_f32": (c_int, [c_int, c_int, c_float, P, P, P]),
+    "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "sed_ms_nms_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C sed-net_amd/csrc`). "
+            "There is no CPU fallback for the SED-Net HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header / library drift
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+_STATUS = {-1: "SED_EINVAL (bad argument)", -2: "SED_EUNSUPPORTED (size outside the instantiated range)"}
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"libsedhip: {what} failed with status {status} {_STATUS.get(status, '(hipError_t)')}")
+
+
+def ptr(t):
+    """device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError("libsedhip needs contiguous tensors")
+    if not t.is_cuda:
+        raise RuntimeError("libsedhip needs tensors resident on the GPU (no CPU fallback)")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

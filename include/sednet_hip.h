@@ -64,6 +64,42 @@ size_t sed_ms_nms_workspace_bytes(int B, int N);
 int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, const float* bw, int* labels,
                    int* centre_ids, int* n_centres, int* n_labels, void* ws, size_t ws_bytes, sed_stream_t stream);
 
+/* ---- DGCNN backbone ---------------------------------------------------------------------------------- */
+/* Fused EdgeConv (gather + [x_j - x_i ; x_i] + Conv2d 1x1 + GroupNorm statistics + max over k).
+ * x [B,N,ldx] point-major with C in {6, 64} real channels; idx [B,N,k]; W1t/W2t [C][Cout] = transposed
+ * difference / centre halves of the conv weight; sgn [Cout] = +1 where GroupNorm gamma >= 0 else -1.
+ * -> ysel [B,N,Cout] (max_k y where gamma >= 0 else min_k y), stats [B][G][2] = (mean, rstd).
+ * src/PointNet.py:150-171 + src/SEDNet.py:37-45 + :82 */
+size_t sed_edgeconv_partials_bytes(int B, int N, int Cout);
+int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
+                         const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
+                         void* partials, size_t partials_bytes, sed_stream_t stream);
+/* Point-wise conv as GEMM: Y = X Wt + bias + cbias[b]; flags 1 ReLU | 2 store Y | 4 GroupNorm partial sums |
+ * 8 per-channel max/min over points. Wt [K][Coutp] zero padded (K % 32 == 0, Coutp % 64 == 0).
+ * src/SEDNet.py:94 (mlp1), :303-329 (heads) */
+size_t sed_pointwise_partials_bytes(int B, int N, int Coutp);
+size_t sed_pointwise_colext_bytes(int B, int N, int Coutp);
+int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
+                          const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
+                          int flags, sed_stream_t stream);
+/* (mean, rstd) per (cloud, group) from the partial sums of sed_pointwise_fwd_f32.  torch.nn.GroupNorm */
+int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps, const void* partials, float* stats,
+                        sed_stream_t stream);
+/* out = scale * act(GN(Y)) + addend (stats NULL: no norm; act 0 none, 1 ReLU, 2 LeakyReLU(slope)).
+ * src/SEDNet.py:303-326 (bn* + relu, and the w_pos_enc fusion adds at :322, :326) */
+int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int ldy, const float* stats, const float* gamma,
+                     const float* beta, int act, float slope, float scale, const float* addend, int lda, float* out,
+                     int ldo, sed_stream_t stream);
+/* x4[b][o] = relu(GN(max/min over N)) from the column extrema of mlp1.   src/SEDNet.py:95-96 */
+int sed_colext_finalize_f32(int B, int N, int C, int G, const void* colext, const float* stats, const float* gamma,
+                            const float* beta, float* out, sed_stream_t stream);
+/* out[b][o] = bias[o] + sum_c W[o][c] v[b][c]: the repeated-global-feature part of conv1 collapses to a
+ * per-cloud bias.   src/SEDNet.py:300-303 */
+int sed_gemv_bias_f32(int B, int Cout, int K, const float* W, int ldw, const float* bias, const float* v, float* out,
+                      int ldo, sed_stream_t stream);
+/* row-wise log-softmax over C channels.   src/SEDNet.py:313 */
+int sed_log_softmax_f32(size_t rows, int C, const float* in, int ld, float* out, int ldo, sed_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

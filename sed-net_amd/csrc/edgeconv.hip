@@ -1,0 +1,205 @@
+// Fused EdgeConv: neighbour gather + (x_j - x_i ; x_i) + 1x1 conv + GroupNorm statistics + max over k,
+// without materialising the [B,2C,N,k] graph feature or the [B,Cout,N,k] conv output.
+//
+// Replaces, per encoder layer, /root/reference/src/PointNet.py:150-171 (get_graph_feature gather/cat/permute)
+// + /root/reference/src/SEDNet.py:37-45 (Conv2d 1x1 no bias -> GroupNorm -> LeakyReLU) + :82 (max over k).
+//
+//   y[p, j, o] = sum_c W[o, c] (x[nbr(p,j), c] - x[p, c]) + sum_c W[o, C + c] x[p, c]
+// The centre term is computed once per point and used as the MFMA accumulator's initial value of every
+// neighbour; the difference x_j - x_i is formed explicitly in fp32 exactly as the reference does (no
+// W1 x_j + (W2 - W1) x_i refactoring, which would change the rounding of near-duplicate neighbours).
+// GroupNorm needs statistics over all (C/G, N, k) values before the activation can be applied, but
+// LeakyReLU(affine(.)) is monotone per channel, so max_k commutes with it: this kernel emits, per
+// (point, channel), max_k y if gamma >= 0 else min_k y, plus deterministic per-workgroup partial sums
+// (sum y, sum y^2, fp64); edgeconv_finalize turns them into mean / rstd and gn_apply (pointwise.hip)
+// produces LeakyReLU(GN(.)).
+//
+// Layout: lane = (point | out-channel, hi); one wave owns 32 points x 64 output channels (two 32x32 fp32
+// MFMA tiles); 4 waves per workgroup share the weight slab in LDS; blockIdx.z selects the 64-channel slab.
+// Neighbour rows are gathered straight from L2 (x is 2.5 MB per cloud) with the next neighbour's row
+// prefetched under the current neighbour's MFMAs.
+#include "common.h"
+
+namespace {
+
+template <int CH>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
+__global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restrict__ x, int ldx,
+                                                          const int* __restrict__ idx, int k,
+                                                          const float* __restrict__ W1t,
+                                                          const float* __restrict__ W2t, int Cout,
+                                                          const float* __restrict__ sgn,
+                                                          float* __restrict__ ysel, double* __restrict__ part,
+                                                          int N) {
+    constexpr int C = 2 * CH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w1 = smem;                // [C][64]
+    float* w2 = smem + C * 64;       // [C][64]
+    double* red = (double*)(smem + 2 * C * 64);   // [4 waves][2 tiles][2]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y, slab = blockIdx.z, o0 = slab * 64;
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, o = i & 63;
+        w1[i] = W1t[(size_t)c * Cout + o0 + o];
+        w2[i] = W2t[(size_t)c * Cout + o0 + o];
+    }
+    __syncthreads();
+
+    const int p0 = blockIdx.x * 128 + wave * 32;
+    const int p = p0 + li;
+    const int pc = p < N ? p : N - 1;
+    const float* xb = x + (size_t)cloud * N * ldx;
+    const int* ib = idx + ((size_t)cloud * N + pc) * k;
+
+    auto load_row = [&](int row, float (&dst)[CH]) {
+        const float* src = xb + (size_t)row * ldx + hi * CH;
+        if (CH % 4 == 0) {
+#pragma unroll
+            for (int s = 0; s < CH; s += 4) {
+                const f32x4 v = *(const f32x4*)(src + s);
+                dst[s] = v[0]; dst[s + 1] = v[1]; dst[s + 2] = v[2]; dst[s + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < CH; ++s) dst[s] = src[s];
+        }
+    };
+
+    float xc[CH];
+    load_row(pc, xc);
+    // centre term: base[t] = sum_c W2t[c][o] x_p[c]
+    f32x16 base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) base[t] = mfma32(xc[s], w2[(hi * CH + s) * 64 + 32 * t + li], base[t]);
+
+    float sg[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) sg[t] = sgn[o0 + 32 * t + li];
+    f32x16 sel[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sel[t][r] = -3.0e38f;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vmask |= (p0 + mfma_row(r, hi) < N ? 1u : 0u) << r;
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+
+    float nxt[CH];
+    load_row(ib[0], nxt);
+    for (int j = 0; j < k; ++j) {
+        float diff[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) diff[s] = nxt[s] - xc[s];         // feature - x   (PointNet.py:170)
+        if (j + 1 < k) load_row(ib[j + 1], nxt);
+        f32x16 acc[2] = {base[0], base[1]};
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = mfma32(diff[s], w1[(hi * CH + s) * 64 + 32 * t + li], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float ps = 0.f, pq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r];
+                sel[t][r] = fmaxf(sel[t][r], sg[t] * v);
+                const float vm = (vmask >> r) & 1u ? v : 0.f;
+                ps += vm;
+                pq = fmaf(vm, vm, pq);
+            }
+            s1[t] += (double)ps;
+            s2[t] += (double)pq;
+        }
+    }
+
+    // selected extreme per (point, channel): lanes = consecutive channels -> coalesced rows
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = p0 + mfma_row(r, hi);
+            if (row < N) ysel[((size_t)cloud * N + row) * Cout + o0 + 32 * t + li] = sg[t] * sel[t][r];
+        }
+
+    // deterministic partial statistics: wave reduce -> LDS -> thread 0
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1[t] += __shfl_xor(s1[t], off, 64);
+            s2[t] += __shfl_xor(s2[t], off, 64);
+        }
+        if (lane == 0) { red[(wave * 2 + t) * 2] = s1[t]; red[(wave * 2 + t) * 2 + 1] = s2[t]; }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int t = tid >> 1, which = tid & 1;
+        double a = 0.0;
+        for (int w = 0; w < 4; ++w) a += red[(w * 2 + t) * 2 + which];
+        const int ntile = Cout / 32;
+        part[(((size_t)cloud * gridDim.x + blockIdx.x) * ntile + slab * 2 + t) * 2 + which] = a;
+    }
+}
+
+// mean / rstd per (cloud, group) from per-block, per-32-channel-tile partial sums (fixed order, fp64)
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
+                                   float eps, float* __restrict__ stats /*[B][G][2]*/) {
+    const int cloud = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    const int tpg = ntile / G;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int t = g * tpg; t < (g + 1) * tpg; ++t) {
+            const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)cloud * G + g) * 2] = (float)mean;
+    stats[((size_t)cloud * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+}  // namespace
+
+extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
+    return (size_t)B * ((N + 127) / 128) * (Cout / 32) * 2 * sizeof(double);
+}
+
+// x [B,N,ldx] point-major (C real channels, C in {6, 64}); idx [B,N,k]; W1t/W2t [C][Cout] = the
+// transposed halves of the Conv2d weight (difference part / centre part); sgn [Cout] = +1 where the
+// GroupNorm gamma >= 0 else -1. Outputs: ysel [B,N,Cout], stats [B][G][2] = (mean, rstd) over all N*k*(Cout/G).
+extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
+                                    const int* idx, const float* W1t, const float* W2t, const float* sgn, float eps,
+                                    float* ysel, float* stats, void* partials, size_t partials_bytes,
+                                    hipStream_t stream) {
+    if (B <= 0 || N <= 0 || k <= 0 || !x || !idx || !W1t || !W2t || !sgn || !ysel || !stats || !partials)
+        return SED_EINVAL;
+    if (Cout % 64 != 0 || G <= 0 || (Cout / G) % 32 != 0 || ldx < C) return SED_EUNSUPPORTED;
+    if (partials_bytes < sed_edgeconv_partials_bytes(B, N, Cout)) return SED_EINVAL;
+    const int nblk = (N + 127) / 128;
+    dim3 grid(nblk, B, Cout / 64), block(256);
+    double* part = (double*)partials;
+    if (C == 6) {
+        const size_t sm = 2 * 6 * 64 * sizeof(float) + 16 * sizeof(double);
+        edgeconv_kernel<3><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N);
+    } else if (C == 64) {
+        if (ldx % 4 != 0) return SED_EUNSUPPORTED;
+        const size_t sm = 2 * 64 * 64 * sizeof(float) + 16 * sizeof(double);
+        edgeconv_kernel<32><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N);
+    } else {
+        return SED_EUNSUPPORTED;
+    }
+    SED_LAUNCH_CHECK();
+    gn_finalize_kernel<<<B, 64, 0, stream>>>(part, nblk, Cout / 32, G, (double)(Cout / G) * N * k, eps, stats);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

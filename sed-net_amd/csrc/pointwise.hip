@@ -1,0 +1,335 @@
+// Point-wise (kernel-1) convolutions of the SED-Net encoder tail and heads as fp32-MFMA GEMMs with fused
+// bias / per-cloud bias / ReLU / GroupNorm statistics / column extrema, plus the small kernels around them.
+//
+// Replaces /root/reference/src/SEDNet.py:94-96 (mlp1 -> GroupNorm(8) -> ReLU -> max over N) and :300-329
+// (conv1, conv2, type / edge / embedding heads: Conv1d -> GroupNorm -> ReLU chains).
+//
+//   Y[b, p, o] = sum_c X[b, p, c] Wt[c, o] + bias[o] + cbias[b, o]
+// X is point-major [B,N,ldx]; a workgroup owns 128 points x BN channels (BN = 128 or 64), 4 waves x 32
+// points, K streamed in chunks of 32 through a double-buffered LDS ring (A tile row stride 36 floats ->
+// conflict-free ds_read_b128; B tile rows read as consecutive floats). v_mfma_f32_32x32x2_f32 keeps fp32
+// exactness (fma chains), which the parity bar needs.
+// GroupNorm over (C/G, N) needs global statistics: the epilogue emits deterministic per-workgroup fp64
+// partial sums per 32-channel tile; gn_finalize reduces them in fixed order; gn_apply applies
+// scale/shift + activation (+ optional `out = scale * act(.) + addend` for the feature-fusion adds at
+// SEDNet.py:322,326). For mlp1 only max_N relu(GN(y)) is needed, and relu(affine) is monotone per channel,
+// so the epilogue keeps per-channel max/min over the tile instead of writing the [N,1024] tensor.
+#include "common.h"
+
+namespace {
+
+enum { F_RELU = 1, F_STORE = 2, F_STATS = 4, F_COLEXT = 8 };
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void pointwise_kernel(const float* __restrict__ X, int ldx, int K,
+                                                           const float* __restrict__ Wt, int ldw,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ cbias, float* __restrict__ Y,
+                                                           int ldy, int Cout, double* __restrict__ part,
+                                                           float* __restrict__ colext, int N, int flags) {
+    constexpr int BN = 32 * TN;
+    constexpr int LDA = 36;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][128][LDA]
+    float* Bs = smem + 2 * 128 * LDA;       // [2][32][BN]
+    double* red = (double*)(Bs + 2 * 32 * BN);   // [4][TN][2]
+    float* ext = (float*)(red + 4 * TN * 2);      // [4][BN][2]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y, o0 = blockIdx.z * BN;
+    const int p0 = blockIdx.x * 128;
+    const float* Xc = X + (size_t)cloud * N * ldx;
+    const int nchunk = K / 32;
+
+    f32x4 sa[4], sb[TN];
+    auto stage_load = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, row = i >> 3, c4 = i & 7;
+            int p = p0 + row;
+            if (p >= N) p = N - 1;
+            sa[u] = *(const f32x4*)(Xc + (size_t)p * ldx + ch * 32 + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int i = tid + 256 * u, row = i / (BN / 4), c4 = i % (BN / 4);
+            sb[u] = *(const f32x4*)(Wt + (size_t)(ch * 32 + row) * ldw + o0 + 4 * c4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, row = i >> 3, c4 = i & 7;
+            *(f32x4*)(As + (buf * 128 + row) * LDA + 4 * c4) = sa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int i = tid + 256 * u, row = i / (BN / 4), c4 = i % (BN / 4);
+            *(f32x4*)(Bs + (buf * 32 + row) * BN + 4 * c4) = sb[u];
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) stage_load(ch + 1);
+        const float* a = As + (cur * 128 + wave * 32 + li) * LDA + hi * 16;
+        const float* b = Bs + (cur * 32 + hi * 16) * BN + li;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 av = *(const f32x4*)(a + 4 * s4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) acc[t] = mfma32(av[c], b[(4 * s4 + c) * BN + 32 * t], acc[t]);
+        }
+        if (ch + 1 < nchunk) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue
+    const int pw = p0 + wave * 32;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vmask |= (pw + mfma_row(r, hi) < N ? 1u : 0u) << r;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int o = o0 + 32 * t + li;
+        float add = bias ? bias[o] : 0.f;
+        if (cbias) add += cbias[(size_t)cloud * ldw + o];
+        float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + add;
+            if (flags & F_RELU) v = fmaxf(v, 0.f);
+            const bool ok = (vmask >> r) & 1u;
+            if ((flags & F_STORE) && ok && o < Cout)
+                Y[((size_t)cloud * N + pw + mfma_row(r, hi)) * ldy + o] = v;
+            if (ok) { ps += v; pq = fmaf(v, v, pq); mx = fmaxf(mx, v); mn = fminf(mn, v); }
+        }
+        if (flags & F_STATS) {
+            double d1 = (double)ps, d2 = (double)pq;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+            if (lane == 0) { red[(wave * TN + t) * 2] = d1; red[(wave * TN + t) * 2 + 1] = d2; }
+        }
+        if (flags & F_COLEXT) {
+            mx = fmaxf(mx, xor32(mx));
+            mn = fminf(mn, xor32(mn));
+            if (hi == 0) { ext[(wave * BN + 32 * t + li) * 2] = mx; ext[(wave * BN + 32 * t + li) * 2 + 1] = mn; }
+        }
+    }
+    if (flags & (F_STATS | F_COLEXT)) __syncthreads();
+    if ((flags & F_STATS) && tid < TN * 2) {
+        const int t = tid >> 1, which = tid & 1;
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += red[(w * TN + t) * 2 + which];
+        const int ntile = gridDim.z * TN;
+        part[(((size_t)cloud * gridDim.x + blockIdx.x) * ntile + blockIdx.z * TN + t) * 2 + which] = s;
+    }
+    if ((flags & F_COLEXT) && tid < BN) {
+        float mx = -3.0e38f, mn = 3.0e38f;
+        for (int w = 0; w < 4; ++w) { mx = fmaxf(mx, ext[(w * BN + tid) * 2]); mn = fminf(mn, ext[(w * BN + tid) * 2 + 1]); }
+        float* dst = colext + (((size_t)cloud * gridDim.x + blockIdx.x) * ldw + o0 + tid) * 2;
+        dst[0] = mx;
+        dst[1] = mn;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
+                                   float eps, float* __restrict__ stats) {
+    const int cloud = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    const int tpg = ntile / G;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int t = g * tpg; t < (g + 1) * tpg; ++t) {
+            const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)cloud * G + g) * 2] = (float)mean;
+    stats[((size_t)cloud * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// out = scale * act(Y * a + b) + addend ;  a = rstd_g gamma_o ; b = beta_o - mean_g a
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ Y, int ldy, int C, int G,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int act, float slope,
+                                                       float scale, const float* __restrict__ addend, int lda,
+                                                       float* __restrict__ out, int ldo, int N) {
+    const int cloud = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // over N * C/4
+    const int c4n = C / 4;
+    if (i >= (size_t)N * c4n) return;
+    const int p = i / c4n, c = (i % c4n) * 4;
+    const size_t row = (size_t)cloud * N + p;
+    const f32x4 y = *(const f32x4*)(Y + row * ldy + c);
+    f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+    if (addend) ad = *(const f32x4*)(addend + row * lda + c);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float v = y[u];
+        if (stats) {
+            const int g = (c + u) / (C / G);
+            const float mean = stats[((size_t)cloud * G + g) * 2], rstd = stats[((size_t)cloud * G + g) * 2 + 1];
+            const float a = rstd * gamma[c + u];
+            const float b = fmaf(-a, mean, beta[c + u]);
+            v = fmaf(v, a, b);
+        }
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v >= 0.f ? v : v * slope;
+        o[u] = addend ? __fadd_rn(__fmul_rn(scale, v), ad[u]) : scale * v;   // (w * a) + x, SEDNet.py:322,326
+    }
+    *(f32x4*)(out + row * ldo + c) = o;
+}
+
+// x4[b][o] = relu(GN(extreme over N)) from per-block column extrema (mlp1 + bnmlp1 + max over N)
+__global__ void colext_finalize_kernel(const float* __restrict__ colext, int nblk, int ldw, int C, int G,
+                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ out) {
+    const int cloud = blockIdx.y, o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= C) return;
+    float mx = -3.0e38f, mn = 3.0e38f;
+    for (int b = 0; b < nblk; ++b) {
+        const float* src = colext + (((size_t)cloud * nblk + b) * ldw + o) * 2;
+        mx = fmaxf(mx, src[0]);
+        mn = fminf(mn, src[1]);
+    }
+    const int g = o / (C / G);
+    const float mean = stats[((size_t)cloud * G + g) * 2], rstd = stats[((size_t)cloud * G + g) * 2 + 1];
+    const float a = rstd * gamma[o];
+    const float b = fmaf(-a, mean, beta[o]);
+    const float v = fmaf(a >= 0.f ? mx : mn, a, b);
+    out[(size_t)cloud * C + o] = fmaxf(v, 0.f);
+}
+
+// out[b][o] = bias[o] + sum_c W[o][c] v[b][c]   (one wave per output; the repeated-global part of conv1)
+__global__ __launch_bounds__(64) void gemv_bias_kernel(const float* __restrict__ W, int ldw, int K,
+                                                       const float* __restrict__ bias, const float* __restrict__ v,
+                                                       float* __restrict__ out, int Cout, int ldo) {
+    const int cloud = blockIdx.y, o = blockIdx.x, lane = threadIdx.x;
+    const float* w = W + (size_t)o * ldw;
+    const float* x = v + (size_t)cloud * K;
+    float acc = 0.f;
+    for (int c = lane; c < K; c += 64) acc = fmaf(w[c], x[c], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[(size_t)cloud * ldo + o] = acc + (bias ? bias[o] : 0.f);
+}
+
+__global__ void log_softmax_kernel(const float* __restrict__ in, int ld, int C, float* __restrict__ out, int ldo,
+                                   size_t rows) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* x = in + r * ld;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    const float ls = logf(s);
+    for (int c = 0; c < C; ++c) out[r * ldo + c] = (x[c] - m) - ls;
+}
+
+}  // namespace
+
+extern "C" size_t sed_pointwise_partials_bytes(int B, int N, int Coutp) {
+    return (size_t)B * ((N + 127) / 128) * (Coutp / 32) * 2 * sizeof(double);
+}
+extern "C" size_t sed_pointwise_colext_bytes(int B, int N, int Coutp) {
+    return (size_t)B * ((N + 127) / 128) * Coutp * 2 * sizeof(float);
+}
+
+// flags: 1 ReLU, 2 store Y, 4 statistics partials, 8 column extrema.
+// Wt [K][Coutp] (K multiple of 32, Coutp multiple of 64, zero padded), bias [Coutp] or NULL,
+// cbias [B][Coutp] or NULL, Y [B,N,ldy] (first Cout columns written).
+extern "C" int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
+                                     const float* Wt, const float* bias, const float* cbias, float* Y, int ldy,
+                                     void* partials, void* colext, int flags, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !X || !Wt) return SED_EINVAL;
+    if (K % 32 != 0 || Coutp % 64 != 0 || ldx % 4 != 0 || ldx < K || Cout > Coutp) return SED_EUNSUPPORTED;
+    if ((flags & F_STORE) && (!Y || ldy < Cout)) return SED_EINVAL;
+    if ((flags & F_STATS) && !partials) return SED_EINVAL;
+    if ((flags & F_COLEXT) && !colext) return SED_EINVAL;
+    const int nblk = (N + 127) / 128;
+    if (Coutp % 128 == 0) {
+        static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in once per process
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)pointwise_kernel<4>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const size_t sm = (2 * 128 * 36 + 2 * 32 * 128) * sizeof(float) + 4 * 4 * 2 * sizeof(double) + 4 * 128 * 2 * sizeof(float);
+        pointwise_kernel<4><<<dim3(nblk, B, Coutp / 128), 256, sm, stream>>>(
+            X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+    } else {
+        const size_t sm = (2 * 128 * 36 + 2 * 32 * 64) * sizeof(float) + 4 * 2 * 2 * sizeof(double) + 4 * 64 * 2 * sizeof(float);
+        pointwise_kernel<2><<<dim3(nblk, B, Coutp / 64), 256, sm, stream>>>(
+            X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+    }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// stats [B][G][2] = (mean, rstd) from partial sums over `count` values per group
+extern "C" int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps, const void* partials,
+                                   float* stats, hipStream_t stream) {
+    if (B <= 0 || G <= 0 || G > 64 || !partials || !stats || (Coutp / 32) % G != 0) return SED_EINVAL;
+    gn_finalize_kernel<<<B, 64, 0, stream>>>((const double*)partials, (N + 127) / 128, Coutp / 32, G, count, eps, stats);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// out = scale * act(GN(Y)) + addend ; stats NULL -> no normalisation; act 0 none / 1 ReLU / 2 LeakyReLU(slope)
+extern "C" int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int ldy, const float* stats,
+                                const float* gamma, const float* beta, int act, float slope, float scale,
+                                const float* addend, int lda, float* out, int ldo, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !Y || !out || C % 4 != 0 || ldy % 4 != 0 || ldo % 4 != 0) return SED_EINVAL;
+    if (stats && (!gamma || !beta || G <= 0 || C % G != 0)) return SED_EINVAL;
+    if (addend && lda % 4 != 0) return SED_EINVAL;
+    const size_t n = (size_t)N * (C / 4);
+    gn_apply_kernel<<<dim3((unsigned)((n + 255) / 256), B), 256, 0, stream>>>(Y, ldy, C, G ? G : 1, stats, gamma, beta, act,
+                                                                             slope, scale, addend, lda, out, ldo, N);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_colext_finalize_f32(int B, int N, int C, int G, const void* colext, const float* stats,
+                                       const float* gamma, const float* beta, float* out, hipStream_t stream) {
+    if (B <= 0 || !colext || !stats || !gamma || !beta || !out || C % G != 0) return SED_EINVAL;
+    colext_finalize_kernel<<<dim3((C + 255) / 256, B), 256, 0, stream>>>((const float*)colext, (N + 127) / 128, C, C, G, stats,
+                                                                        gamma, beta, out);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_gemv_bias_f32(int B, int Cout, int K, const float* W, int ldw, const float* bias, const float* v,
+                                 float* out, int ldo, hipStream_t stream) {
+    if (B <= 0 || Cout <= 0 || K <= 0 || !W || !v || !out || ldw < K || ldo < Cout) return SED_EINVAL;
+    gemv_bias_kernel<<<dim3(Cout, B), 64, 0, stream>>>(W, ldw, K, bias, v, out, Cout, ldo);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_log_softmax_f32(size_t rows, int C, const float* in, int ld, float* out, int ldo,
+                                   hipStream_t stream) {
+    if (rows == 0 || C <= 0 || !in || !out) return SED_EINVAL;
+    log_softmax_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, stream>>>(in, ld, C, out, ldo, rows);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

@@ -29,6 +29,18 @@ SIGNATURES = {
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_nms_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
+    "sed_edgeconv_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_edgeconv_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P, P,
+                                     P, c_size_t, P]),
+    "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_pointwise_colext_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_pointwise_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_gn_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_double, c_float, P, P, P]),
+    "sed_gn_apply_f32": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_float, c_float, P, c_int,
+                                 P, c_int, P]),
+    "sed_colext_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "sed_gemv_bias_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, P]),
+    "sed_log_softmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, c_int, P]),
 }
 
 

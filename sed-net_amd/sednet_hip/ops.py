@@ -121,3 +121,94 @@ def ms_nms(centres, X, bw):
     check(lib.sed_ms_nms_f32(B, N, D, ptr(centres), ptr(X), ptr(bw), ptr(labels), ptr(ids), ptr(n_c), ptr(n_l),
                              ptr(ws), nbytes, stream()), "ms_nms")
     return labels, ids, n_c, n_l
+
+
+# ---------------------------------------------------------------------------------------------------
+# backbone
+# ---------------------------------------------------------------------------------------------------
+F_RELU, F_STORE, F_STATS, F_COLEXT = 1, 2, 4, 8
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _bytes(n, device):
+    return torch.empty((max(int(n), 8),), dtype=torch.uint8, device=device)
+
+
+def edgeconv(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
+    """x [B,N,ldx] point-major, idx [B,N,k] i32 -> (ysel [B,N,Cout], stats [B,G,2]); see edgeconv.hip."""
+    B, N, ldx = x.shape
+    k = idx.shape[2]
+    Cout = W1t.shape[1]
+    ysel = torch.empty((B, N, Cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    nb = lib.sed_edgeconv_partials_bytes(B, N, Cout)
+    part = _bytes(nb, x.device)
+    check(lib.sed_edgeconv_fwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(sgn),
+                                   float(eps), ptr(ysel), ptr(stats), ptr(part), nb, stream()), "edgeconv_fwd")
+    return ysel, stats
+
+
+def gn_apply(Y, C, G, stats, gamma, beta, act, out, slope=0.0, scale=1.0, addend=None):
+    """out[..., :C] = scale * act(GN(Y[..., :C])) + addend; Y/out/addend are [B,N,ld*] views (row stride = ld)."""
+    B, N = Y.shape[0], Y.shape[1]
+    check(lib.sed_gn_apply_f32(B, N, C, G, _vptr(Y), Y.stride(1), ptr(stats) if stats is not None else None,
+                               ptr(gamma) if gamma is not None else None, ptr(beta) if beta is not None else None,
+                               act, float(slope), float(scale), _vptr(addend) if addend is not None else None,
+                               addend.stride(1) if addend is not None else 0, _vptr(out), out.stride(1), stream()),
+          "gn_apply")
+    return out
+
+
+def _vptr(t):
+    """pointer of a [B,N,C] column-slice view of a contiguous [B,N,ld] buffer."""
+    assert t.is_cuda and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "need a row-strided view"
+    return _lib.c_void_p(t.data_ptr())
+
+
+def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5):
+    """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp].
+    Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
+    B, N = X.shape[0], X.shape[1]
+    K, Coutp = Wt.shape
+    dev = X.device
+    if (flags & F_STORE) and out is None:
+        out = torch.empty((B, N, Coutp), dtype=torch.float32, device=dev)[:, :, :Cout]
+    part = _bytes(lib.sed_pointwise_partials_bytes(B, N, Coutp), dev) if flags & F_STATS else None
+    colext = _bytes(lib.sed_pointwise_colext_bytes(B, N, Coutp), dev) if flags & F_COLEXT else None
+    check(lib.sed_pointwise_fwd_f32(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), ptr(Wt),
+                                    ptr(bias) if bias is not None else None,
+                                    ptr(cbias) if cbias is not None else None,
+                                    _vptr(out) if out is not None else None, out.stride(1) if out is not None else 0,
+                                    ptr(part) if part is not None else None,
+                                    ptr(colext) if colext is not None else None, flags, stream()), "pointwise_fwd")
+    stats = None
+    if flags & F_STATS:
+        stats = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+        check(lib.sed_gn_finalize_f32(B, N, Coutp, G, float((Coutp // G) * N), float(eps), ptr(part), ptr(stats),
+                                      stream()), "gn_finalize")
+    return out, stats, colext
+
+
+def colext_finalize(colext, B, N, C, G, stats, gamma, beta):
+    out = torch.empty((B, C), dtype=torch.float32, device=stats.device)
+    check(lib.sed_colext_finalize_f32(B, N, C, G, ptr(colext), ptr(stats), ptr(gamma), ptr(beta), ptr(out), stream()),
+          "colext_finalize")
+    return out
+
+
+def gemv_bias(W, ldw, K, bias, v):
+    """out[b,o] = bias[o] + sum_{c<K} W[o,c] v[b,c]; W rows have stride ldw."""
+    B = v.shape[0]
+    Cout = W.shape[0]
+    out = torch.empty((B, Cout), dtype=torch.float32, device=v.device)
+    check(lib.sed_gemv_bias_f32(B, Cout, K, ptr(W), ldw, ptr(bias) if bias is not None else None, ptr(v), ptr(out),
+                                Cout, stream()), "gemv_bias")
+    return out
+
+
+def log_softmax_rows(X, C):
+    """X [B,N,ld] view -> [B,N,C] log-softmax over the first C columns."""
+    B, N = X.shape[0], X.shape[1]
+    out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
+    check(lib.sed_log_softmax_f32(B * N, C, _vptr(X), X.stride(1), ptr(out), C, stream()), "log_softmax")
+    return out

@@ -1,0 +1,236 @@
+"""SEDNet / DGCNNEncoderGn -- same constructor, state-dict keys and forward contract as
+/root/reference/src/SEDNet.py:19-98 and :216-342, executed on gfx950 by libsedhip.so.
+
+The torch.nn layers below are parameter containers only (so that reference checkpoints load unchanged,
+SURVEY.md section 5); forward() never calls them. Activations live point-major [B,N,C] on the device:
+    kNN (pairwise rows + exact selection) -> fused EdgeConv (gather + conv + GroupNorm statistics + max_k)
+    x3 -> mlp1 with fused GroupNorm statistics + max over N -> head GEMMs with fused statistics.
+Inference only (no autograd through the HIP kernels).
+"""
+import torch
+import torch.nn as nn
+
+from sednet_hip import ops
+
+
+def _wt(conv, k_pad=None, cols=None):
+    """Conv1d/Conv2d kernel-1 weight [Cout,Cin,...] -> transposed, zero padded [Kp, Coutp] + padded bias."""
+    W = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
+    if cols is not None:
+        W = W[:, cols[0]:cols[1]]
+    Cout, K = W.shape
+    Kp = (K + 31) // 32 * 32 if k_pad is None else k_pad
+    Coutp = (Cout + 63) // 64 * 64
+    Wt = torch.zeros((Kp, Coutp), dtype=torch.float32, device=W.device)
+    Wt[:K, :Cout] = W.t()
+    b = None
+    if conv.bias is not None:
+        b = torch.zeros((Coutp,), dtype=torch.float32, device=W.device)
+        b[:Cout] = conv.bias.detach().float()
+    return Wt.contiguous(), b
+
+
+class DGCNNEncoderGn(nn.Module):
+    def __init__(self, mode=0, input_channels=3, nn_nb=80, normal_metric_W=1.):
+        super(DGCNNEncoderGn, self).__init__()
+        self.k = nn_nb
+        self.dilation_factor = 1
+        self.mode = mode
+        self.drop = 0.0
+        self.input_channels = input_channels
+        self.normal_metric_W = normal_metric_W
+        if self.mode == 0 or self.mode == 5:
+            self.bn1 = nn.GroupNorm(2, 64)
+            self.bn2 = nn.GroupNorm(2, 64)
+            self.bn3 = nn.GroupNorm(2, 128)
+            self.bn4 = nn.GroupNorm(4, 256)      # dead weights in the reference too (state-dict parity)
+            self.bn5 = nn.GroupNorm(8, 1024)
+            self.conv1 = nn.Sequential(nn.Conv2d(input_channels * 2, 64, kernel_size=1, bias=False), self.bn1,
+                                       nn.LeakyReLU(negative_slope=0.2))
+            self.conv2 = nn.Sequential(nn.Conv2d(64 * 2, 64, kernel_size=1, bias=False), self.bn2,
+                                       nn.LeakyReLU(negative_slope=0.2))
+            self.conv3 = nn.Sequential(nn.Conv2d(64 * 2, 128, kernel_size=1, bias=False), self.bn3,
+                                       nn.LeakyReLU(negative_slope=0.2))
+            self.mlp1 = nn.Conv1d(256, 1024, 1)
+            self.bnmlp1 = nn.GroupNorm(8, 1024)
+        self._cache = None
+
+    # -- weights in kernel layout --------------------------------------------------------------------
+    def _prepared(self):
+        if self._cache is None:
+            c = {}
+            for i, (conv, bn) in enumerate(((self.conv1[0], self.bn1), (self.conv2[0], self.bn2),
+                                            (self.conv3[0], self.bn3)), 1):
+                W = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
+                C = W.shape[1] // 2
+                g = bn.weight.detach().float().contiguous()
+                c[f"e{i}"] = (W[:, :C].t().contiguous(), W[:, C:].t().contiguous(),
+                              torch.where(g >= 0, 1.0, -1.0).float().contiguous(), g,
+                              bn.bias.detach().float().contiguous(), bn.num_groups, bn.eps)
+            c["mlp1"] = _wt(self.mlp1)
+            c["bnmlp1"] = (self.bnmlp1.weight.detach().float().contiguous(),
+                           self.bnmlp1.bias.detach().float().contiguous())
+            self._cache = c
+        return self._cache
+
+    def _edge(self, key, x, C, idx, out_views):
+        W1t, W2t, sgn, gamma, beta, G, eps = self._prepared()[key]
+        ysel, stats = ops.edgeconv(x, C, idx, W1t, W2t, sgn, G, eps)
+        for o in out_views:
+            ops.gn_apply(ysel, ysel.shape[2], G, stats, gamma, beta, ops.ACT_LEAKY, o, slope=0.2)
+
+    def forward_point_major(self, x):
+        """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major)."""
+        if self.mode != 5 or self.input_channels != 6:
+            raise NotImplementedError("the HIP path implements mode 5 with xyz+normal input (the SED-Net configuration)")
+        B, _, N = x.shape
+        k = self.k
+        x = x.detach().float().contiguous()
+        dev = x.device
+        feats = torch.empty((B, N, 256), dtype=torch.float32, device=dev)
+        x8 = torch.zeros((B, N, 8), dtype=torch.float32, device=dev)
+        x8[:, :, :6] = x.transpose(1, 2)
+        idx = ops.knn_points_normals(x, k, self.normal_metric_W)
+        x1 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
+        self._edge("e1", x8, 6, idx, (x1, feats[:, :, 0:64]))
+        idx = ops.knn_features(x1, k, 64)
+        x2 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
+        self._edge("e2", x1, 64, idx, (x2, feats[:, :, 64:128]))
+        idx = ops.knn_features(x2, k, 64)
+        self._edge("e3", x2, 64, idx, (feats[:, :, 128:256],))
+        Wt, b = self._prepared()["mlp1"]
+        gamma, beta = self._prepared()["bnmlp1"]
+        _, stats, colext = ops.pointwise(feats, Wt, 1024, bias=b, flags=ops.F_STATS | ops.F_COLEXT, G=8,
+                                         eps=self.bnmlp1.eps)
+        x4 = ops.colext_finalize(colext, B, N, 1024, 8, stats, gamma, beta)
+        return x4, feats
+
+    def forward(self, x):
+        """SEDNet.py:78-98 -> (x4 [B,1024], x_features [B,256,N])."""
+        x4, feats = self.forward_point_major(x)
+        return x4, feats.transpose(1, 2).contiguous()
+
+    def load_state_dict(self, *a, **k):
+        self._cache = None
+        return super().load_state_dict(*a, **k)
+
+
+class SEDNet(nn.Module):
+    def __init__(self, emb_size=50, num_primitives=8, primitives=False, embedding=False, mode=0, num_channels=3,
+                 loss_function=None, nn_nb=80, combine_label_prim=False, edge_module=False, late_fusion=False,
+                 w_pos_enc=0.2, normal_metric_W=1., predict_normal=False):
+        super(SEDNet, self).__init__()
+        self.mode = mode
+        self.encoder = DGCNNEncoderGn(mode=mode, input_channels=num_channels, nn_nb=nn_nb,
+                                      normal_metric_W=normal_metric_W)
+        self.drop = 0.0
+        self.loss_function = loss_function
+        self.w_pos_enc = w_pos_enc
+        self.conv1 = torch.nn.Conv1d(1024 + 256, 512, 1)
+        self.bn1 = nn.GroupNorm(8, 512)
+        self.conv2 = torch.nn.Conv1d(512, 256, 1)
+        self.bn2 = nn.GroupNorm(4, 256)
+        self.emb_size = emb_size
+        self.primitives = primitives
+        self.embedding = embedding
+        self.combine_label_prim = combine_label_prim
+        self.late_fusion = late_fusion
+        self.edge_module = None
+        if edge_module:
+            self.edge_module = nn.Sequential(torch.nn.Conv1d(256, 128, 1), nn.GroupNorm(4, 128),
+                                             torch.nn.Conv1d(128, 2, 1))
+        if self.combine_label_prim:
+            self.asis = nn.Sequential(torch.nn.Conv1d(256, 256, 1), nn.GroupNorm(4, 256), nn.ReLU(True),
+                                      nn.Dropout(0.0))
+        if self.embedding:
+            self.mlp_seg_prob1 = torch.nn.Conv1d(256, 256, 1)
+            self.mlp_seg_prob2 = torch.nn.Conv1d(256, self.emb_size, 1)
+            self.bn_seg_prob1 = nn.GroupNorm(4, 256)
+        if primitives:
+            self.mlp_prim_prob1 = torch.nn.Conv1d(256, 256, 1)
+            self.mlp_prim_prob2 = torch.nn.Conv1d(256, num_primitives, 1)
+            self.bn_prim_prob1 = nn.GroupNorm(4, 256)
+        self.num_primitives = num_primitives
+        self.predict_normal = predict_normal
+        if predict_normal:
+            raise NotImplementedError("predict_normal is off in every SED-Net script; not on the HIP path")
+        self.prim_encoding = nn.Sequential(nn.Conv1d(8, 256, 1), nn.ReLU())
+        self._cache = None
+
+    def load_state_dict(self, state_dict, *a, **k):
+        self._cache = None
+        self.encoder._cache = None
+        return super().load_state_dict(state_dict, *a, **k)
+
+    def _apply(self, fn, *a, **k):        # .cuda() / .to(): drop device-side weight caches
+        self._cache = None
+        self.encoder._cache = None
+        return super()._apply(fn, *a, **k)
+
+    def _prepared(self):
+        if self._cache is None:
+            gb = lambda m: (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous())
+            c = {
+                "conv1_g": self.conv1.weight.detach().float().reshape(512, 1280).contiguous(),
+                "conv1_b": self.conv1.bias.detach().float().contiguous(),
+                "conv1_f": _wt(self.conv1, cols=(1024, 1280))[0],
+                "bn1": gb(self.bn1),
+                "conv2": _wt(self.conv2), "bn2": gb(self.bn2),
+                "prim1": _wt(self.mlp_prim_prob1), "bn_prim1": gb(self.bn_prim_prob1),
+                "prim2": _wt(self.mlp_prim_prob2),
+                "edge0": _wt(self.edge_module[0]), "edge1": gb(self.edge_module[1]), "edge2": _wt(self.edge_module[2]),
+                "seg1": _wt(self.mlp_seg_prob1), "bn_seg1": gb(self.bn_seg_prob1), "seg2": _wt(self.mlp_seg_prob2),
+                "asis0": _wt(self.asis[0]), "asis1": gb(self.asis[1]),
+                "penc": _wt(self.prim_encoding[0]),
+            }
+            self._cache = c
+        return self._cache
+
+    def _conv_gn_relu(self, X, conv_key, bn_key, G, C, eps, act=ops.ACT_RELU, scale=1.0, addend=None, cbias=None,
+                      Wt=None, bias=None):
+        c = self._prepared()
+        if Wt is None:
+            Wt, bias = c[conv_key]
+        Y, stats, _ = ops.pointwise(X, Wt, C, bias=bias, cbias=cbias, flags=ops.F_STORE | ops.F_STATS, G=G, eps=eps)
+        gamma, beta = c[bn_key]
+        return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend)
+
+    def forward(self, points, labels=None, compute_loss=False):
+        """SEDNet.py:292-342 -> [embedding [B,emb,N], log_prob [B,P,N], embed_loss [1], edges [B,2,N]]."""
+        if not (self.primitives and self.embedding and self.edge_module is not None and self.combine_label_prim
+                and self.late_fusion):
+            raise NotImplementedError("the HIP path implements the configuration used by the SED-Net scripts "
+                                      "(embedding, primitives, edge_module, combine_label_prim, late_fusion)")
+        if compute_loss:
+            raise NotImplementedError("training losses are outside the inference hot path")
+        with torch.no_grad():
+            c = self._prepared()
+            B, _, N = points.shape
+            dev = points.device
+            x4, feats = self.encoder.forward_point_major(points)
+            # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
+            cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
+            a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"])
+            x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps)                      # :304
+            x_type = self._conv_gn_relu(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps)  # :311
+            P = self.num_primitives
+            te = torch.zeros((B, N, 32), dtype=torch.float32, device=dev)       # cat(type_logit, edges), K padded
+            Wt, b = c["prim2"]
+            ops.pointwise(x_type, Wt, P, bias=b, out=te[:, :, 0:P])                                  # :312
+            log_prob = ops.log_softmax_rows(te, P)                                                      # :313
+            e1 = self._conv_gn_relu(x_type, "edge0", "edge1", 4, 128, self.edge_module[1].eps, act=ops.ACT_NONE)
+            Wt, b = c["edge2"]
+            ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2])                                  # :316-317
+            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps)          # :320
+            x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
+                                   scale=self.w_pos_enc, addend=xs)                                    # :322
+            Wt, b = c["penc"]
+            pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)             # :326
+            x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x)
+            Wt, b = c["seg2"]
+            emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b)                                   # :329
+            embedding = emb.transpose(1, 2).contiguous()
+            primitives_log_prob = log_prob.transpose(1, 2).contiguous()
+            edges_pred = te[:, :, P:P + 2].transpose(1, 2).contiguous()
+            embed_loss = torch.zeros(1, device=dev)                                                    # :335
+        return [embedding, primitives_log_prob, embed_loss, edges_pred]

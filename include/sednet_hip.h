@@ -100,6 +100,23 @@ int sed_gemv_bias_f32(int B, int Cout, int K, const float* W, int ldw, const flo
 /* row-wise log-softmax over C channels.   src/SEDNet.py:313 */
 int sed_log_softmax_f32(size_t rows, int C, const float* in, int ld, float* out, int ldo, sed_stream_t stream);
 
+/* ---- primitive fits + residuals --------------------------------------------------------------------- */
+/* Weighted LSQ fit of one primitive per (cloud, segment); one launch replaces the per-segment Python loop and
+ * its SVD/QR/matrix_rank/cond calls.   src/primitive_forward.py:712-847, :929-1051; src/fitting_utils.py:36-85
+ * points/normals [B,N,3]; labels [B,N] in 0..S-1 or NULL (all points in every segment); seg_type [B,S]:
+ * 1 plane, 3 cone, 4 cylinder, 5 sphere (others skipped); wmode 0 unit weights, 1 weights [B,N], 2 [B,N,S];
+ * params [B,S,8]: plane (a,d) | sphere (c,r) | cylinder (a,c,r) | cone (apex,axis,theta); valid [B,S]. */
+int sed_fit_segments_f32(int B, int N, int S, const float* points, const float* normals, const int* labels,
+                         const int* seg_type, const float* weights, int wmode, float weight_eps, int min_points,
+                         float* params, int* valid, sed_stream_t stream);
+/* Squared (or guarded-sqrt) distance of every point to its segment's primitive + per-segment mean.
+ * src/primitives.py:89-195 (distance_from_*), :36-44 */
+int sed_residual_segments_f32(int B, int N, int S, const float* points, const int* labels, const int* seg_type,
+                              const float* params, const int* valid, int take_sqrt, float* per_point, float* seg_mean,
+                              sed_stream_t stream);
+/* LeastSquares.lstsq for an m x 3 system (QR branch / ridge branch).   src/fitting_utils.py:36-65 */
+int sed_lstsq3_f32(int m, const float* A, const float* Y, float* x, sed_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

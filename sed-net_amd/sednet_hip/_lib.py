@@ -41,6 +41,9 @@ SIGNATURES = {
     "sed_colext_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "sed_gemv_bias_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, P]),
     "sed_log_softmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, c_int, P]),
+    "sed_fit_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, c_int, P, P, P]),
+    "sed_residual_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
+    "sed_lstsq3_f32": (c_int, [c_int, P, P, P, P]),
 }
 
 

@@ -212,3 +212,47 @@ def log_softmax_rows(X, C):
     out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
     check(lib.sed_log_softmax_f32(B * N, C, _vptr(X), X.stride(1), ptr(out), C, stream()), "log_softmax")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# primitive fits / residuals
+# ---------------------------------------------------------------------------------------------------
+PLANE, CONE, CYLINDER, SPHERE = 1, 3, 4, 5
+EPS = 1.1920928955078125e-07
+
+
+def fit_segments(points, normals, seg_type, labels=None, weights=None, weight_eps=EPS, min_points=20):
+    """points/normals [B,N,3]; seg_type [B,S] i32; labels [B,N] i32 or None; weights None | [B,N] | [B,N,S]
+    -> (params [B,S,8], valid [B,S] i32); see fit.hip."""
+    B, N, _ = points.shape
+    S = seg_type.shape[1]
+    dev = points.device
+    params = torch.empty((B, S, 8), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, S), dtype=torch.int32, device=dev)
+    wmode = 0 if weights is None else (1 if weights.dim() == 2 else 2)
+    check(lib.sed_fit_segments_f32(B, N, S, ptr(points), ptr(normals), ptr(labels) if labels is not None else None,
+                                   ptr(seg_type), ptr(weights) if weights is not None else None, wmode,
+                                   float(weight_eps), int(min_points), ptr(params), ptr(valid), stream()),
+          "fit_segments")
+    return params, valid
+
+
+def residual_segments(points, seg_type, params, valid, labels=None, sqrt=False, per_point=True):
+    """-> (per_point [B,N] (labels given) or [B,N,S] (labels None) or None, seg_mean [B,S])."""
+    B, N, _ = points.shape
+    S = seg_type.shape[1]
+    dev = points.device
+    pp = None
+    if per_point:
+        pp = torch.zeros((B, N) if labels is not None else (B, N, S), dtype=torch.float32, device=dev)
+    mean = torch.empty((B, S), dtype=torch.float32, device=dev)
+    check(lib.sed_residual_segments_f32(B, N, S, ptr(points), ptr(labels) if labels is not None else None,
+                                        ptr(seg_type), ptr(params), ptr(valid), 1 if sqrt else 0,
+                                        ptr(pp) if pp is not None else None, ptr(mean), stream()), "residual_segments")
+    return pp, mean
+
+
+def lstsq3(A, Y):
+    x = torch.empty((3,), dtype=torch.float32, device=A.device)
+    check(lib.sed_lstsq3_f32(A.shape[0], ptr(A), ptr(Y), ptr(x), stream()), "lstsq3")
+    return x

@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end SED-Net inference throughput on MI355X (clouds/s), one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path over one batch of synthetic clouds already resident in HBM:
+2 SED-Net forwards (type model + instance model: kNN graph, EdgeConv, heads) -> argmax types, unit embedding ->
+guarded mean-shift (bandwidth, 50 iterations, NMS; x1.2 retries while > 49 clusters) -> per-segment type vote ->
+batched LSQ primitive fits -> residuals. Workload = BASELINE.json configs[2] (64 clouds x 10 000 points per GPU,
+k = 20, full HIP path); with N GPUs every rank owns its own 64 clouds (configs[3]: 512 clouds over 8 GPUs), the
+only collective is the final RCCL all_gather of labels / types / primitive parameters -> weak scaling.
+
+The JSON line also carries
+  roofline     : the dominant kernel (ms_iterate: 94 % of the path's flops), timed live with events on the launch
+                 stream inside the timed region; algorithmic flops 4 N^2 D iters per cloud vs the 157.3 TFLOP/s
+                 fp32-MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (numpy restatement of the reference path, oracle/) timed on this box's host cores
+                 on a bounded sample (rank 0, N = 1 only). A reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sed-net_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clouds", type=int, default=64, help="clouds per GPU per step")
+    ap.add_argument("--points", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--iterations", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_models(k, device):
+    from sednet_hip import synth
+    from src.SEDNet import SEDNet
+    models = []
+    for salt in (0, 1):                       # type model, instance model (generate_predictions_aug.py:142-170)
+        m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+                   combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in synth.closed_form_state_dict(salt).items()})
+        models.append(m.to(device).eval())
+    return models
+
+
+def cpu_baseline(args):
+    """Oracle timed on the host: 1 cloud, 2 forwards + bandwidth + 5 of the 50 mean-shift iterations (scaled x10)
+    + NMS + fits. ~10-30 s of CPU work."""
+    from oracle import backbone, fit as ofit, mean_shift as oms
+    from sednet_hip import synth
+    cores = os.cpu_count() or 1
+    N, k = args.points, args.k
+    p, n, _, _ = synth.synthetic_cloud(1234, N)
+    x = np.concatenate([p, n], 1).T[None].astype(np.float32)
+    t0 = time.perf_counter()
+    _, logp, _ = backbone.sednet_forward(synth.closed_form_state_dict(0), x, k)
+    t_fwd = time.perf_counter() - t0
+    types = np.argmax(logp[0], 0)
+    X, _ = synth.clustered_embedding(N=N, d=128, n_clusters=14, sigma=0.01, seed=1)
+    t0 = time.perf_counter()
+    bw = max(oms.compute_bandwidth(X, 10000, 0.015), np.float32(0.003))
+    t_bw = time.perf_counter() - t0
+    it_s = 5
+    t0 = time.perf_counter()
+    nx = oms.mean_shift_iterations(X, bw, it_s)
+    t_it = (time.perf_counter() - t0) * (args.iterations / it_s)
+    t0 = time.perf_counter()
+    _, _, labels = oms.nms(nx, X, bw)
+    t_nms = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    S = int(labels.max()) + 1
+    seg_types = [int(np.bincount(types[labels == s], minlength=6).argmax()) for s in range(S)]
+    ofit.fit_segments_eval(p, n, labels, [t if t in (1, 3, 4, 5) else 1 for t in seg_types])
+    t_fit = time.perf_counter() - t0
+    total = 2 * t_fwd + t_bw + t_it + t_nms + t_fit
+    return {"value": round(1.0 / total, 5), "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": f"1 cloud x {N} pts, k={k}: oracle forward timed once (x2 models = {2 * t_fwd:.1f}s), "
+                      f"bandwidth {t_bw:.1f}s, {it_s} of {args.iterations} mean-shift iterations scaled "
+                      f"x{args.iterations // it_s} = {t_it:.1f}s, nms {t_nms:.1f}s, fits {t_fit:.2f}s; numpy/BLAS threads = host cores"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sednet_hip import ops, synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    from sednet_hip.shard import gather_results
+
+    B, N = args.clouds, args.points
+    x_np, _, _ = synth.batch_clouds(B, N, seed0=1234 + rank * B)          # this rank's shard of the cloud list
+    x = torch.from_numpy(x_np).to(dev)
+    m_type, m_inst = build_models(args.k, dev)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=args.iterations)
+
+    def step():
+        out = pipe(x)
+        if world > 1:
+            out = gather_results(out, dist)
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ops.TIMERS = []                      # ms_iterate launches record (start, end) events from here on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    timers, ops.TIMERS = ops.TIMERS, None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant kernel: mean of the ms_iterate launch durations inside the timed region
+    it_ms = [s.elapsed_time(e) for (name, s, e, meta) in timers if name == "ms_iterate"]
+    it_clouds = [meta["B"] for (name, s, e, meta) in timers if name == "ms_iterate"]
+    flops_per_cloud = 4.0 * N * N * 128 * args.iterations
+    avg_ms = float(np.mean(it_ms))
+    ach = flops_per_cloud * float(np.mean(it_clouds)) / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_ms_iterate.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+
+    if rank == 0:
+        total_clouds = B * world * args.steps
+        line = {
+            "metric": "point-clouds/sec (10k pts, k=20) end-to-end inference",
+            "value": round(total_clouds / elapsed, 3), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 64 x 10k-point clouds per GPU, k=20, full HIP path "
+                                   "(2 SED-Net forwards + guarded mean-shift + primitive LSQ fits + residuals)",
+                       "clouds_per_gpu": B, "points": N, "k": args.k, "ms_iterations": args.iterations,
+                       "embedding_dim": 128, "weights": "closed-form synthetic", "parallelism": f"cloud-shard x{world}",
+                       "mean_shift_passes_per_cloud": float(np.mean(out["passes"])) if world == 1 else None},
+            "roofline": {"kernel": "ms_iterate_kernel<4>", "bound": "mfma", "achieved": round(ach, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
+                         "flops_per_launch": flops_per_cloud * float(np.mean(it_clouds))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

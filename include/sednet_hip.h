@@ -117,6 +117,17 @@ int sed_residual_segments_f32(int B, int N, int S, const float* points, const in
 /* LeastSquares.lstsq for an m x 3 system (QR branch / ridge branch).   src/fitting_utils.py:36-65 */
 int sed_lstsq3_f32(int m, const float* A, const float* Y, float* x, sed_stream_t stream);
 
+/* ---- stage glue (keeps the batched driver on the device) ----------------------------------------------- */
+/* out[r,:dpad] = in[r,:d] / max(||in[r,:d]||, 1e-12), zero padded.   generate_predictions_aug.py:377,:380 */
+int sed_row_normalize_f32(size_t rows, int d, int dpad, const float* in, int ldi, float* out, int ldo,
+                          sed_stream_t stream);
+/* out[r] = argmax_c in[r,c] (first maximum).   generate_predictions_aug.py:365 */
+int sed_row_argmax_f32(size_t rows, int C, const float* in, int ld, int* out, sed_stream_t stream);
+/* seg_type[b,s] = most frequent types[b, labels[b,:]==s] (ties -> smallest id); seg_count optional.
+ * Fitting_patches_and_edges/residual_utils.py:259 (stats.mode) */
+int sed_segment_type_vote(int B, int N, int S, int C, const int* labels, const int* types, int* seg_type,
+                          int* seg_count, sed_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

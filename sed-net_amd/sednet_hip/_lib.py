@@ -44,6 +44,9 @@ SIGNATURES = {
     "sed_fit_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, c_int, P, P, P]),
     "sed_residual_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "sed_lstsq3_f32": (c_int, [c_int, P, P, P, P]),
+    "sed_row_normalize_f32": (c_int, [c_size_t, c_int, c_int, P, c_int, P, c_int, P]),
+    "sed_row_argmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, P]),
+    "sed_segment_type_vote": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P]),
 }
 
 

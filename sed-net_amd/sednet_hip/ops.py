@@ -9,6 +9,9 @@ from ._lib import check, lib, ptr, stream
 
 # upper bound for the materialised pairwise-row workspace (bytes); clouds are processed in chunks
 PAIR_WS_BYTES = 12 << 30
+# bench.py sets this to a list: launches of the dominant kernel then record (name, start, end, meta) events
+# on the launch stream (torch's current stream is the stream every kernel here is enqueued on)
+TIMERS = None
 
 
 def pad_dim(d):
@@ -103,7 +106,13 @@ def ms_iterate(X, bw, iters):
     """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79)."""
     B, N, D = X.shape
     out = torch.empty_like(X)
+    if TIMERS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.sed_ms_iterate_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), stream()), "ms_iterate")
+    if TIMERS is not None:
+        ev1.record()
+        TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
     return out
 
 
@@ -256,3 +265,33 @@ def lstsq3(A, Y):
     x = torch.empty((3,), dtype=torch.float32, device=A.device)
     check(lib.sed_lstsq3_f32(A.shape[0], ptr(A), ptr(Y), ptr(x), stream()), "lstsq3")
     return x
+
+
+# ---------------------------------------------------------------------------------------------------
+# stage glue
+# ---------------------------------------------------------------------------------------------------
+
+def row_normalize(X, d=None):
+    """X [B,N,ld] view -> unit rows over the first d columns, zero padded to pad_dim(d): [B,N,Dpad]."""
+    B, N = X.shape[0], X.shape[1]
+    d = X.shape[2] if d is None else d
+    dp = pad_dim(d)
+    out = torch.empty((B, N, dp), dtype=torch.float32, device=X.device)
+    check(lib.sed_row_normalize_f32(B * N, d, dp, _vptr(X), X.stride(1), ptr(out), dp, stream()), "row_normalize")
+    return out
+
+
+def row_argmax(X, C):
+    B, N = X.shape[0], X.shape[1]
+    out = torch.empty((B, N), dtype=torch.int32, device=X.device)
+    check(lib.sed_row_argmax_f32(B * N, C, _vptr(X), X.stride(1), ptr(out), stream()), "row_argmax")
+    return out
+
+
+def segment_type_vote(labels, types, S, C=6):
+    B, N = labels.shape
+    seg_type = torch.empty((B, S), dtype=torch.int32, device=labels.device)
+    seg_count = torch.empty((B, S), dtype=torch.int32, device=labels.device)
+    check(lib.sed_segment_type_vote(B, N, S, C, ptr(labels), ptr(types), ptr(seg_type), ptr(seg_count), stream()),
+          "segment_type_vote")
+    return seg_type, seg_count

@@ -1,0 +1,42 @@
+"""Batched, device-resident counterpart of the reference's per-cloud inference loop
+(/root/reference/generate_predictions_aug.py:213-387) extended by the primitive-fit stage whose reference
+caller is Fitting_patches_and_edges/residual_utils.py:86-331:
+
+    type model  -> per-point primitive type (argmax of log-probs)               :224-226, :365
+    inst model  -> per-point embedding -> unit rows                            :227-229, :380
+    guard_mean_shift(quantile 0.015, 50 iterations, x1.2 while > 49 clusters)   :25-35, :382
+    per segment: type vote (stats.mode) -> LSQ fit -> closed-form residual     residual_utils.py:259, :300-331
+
+B clouds go through every stage in one launch each; the only host syncs are the guard loop's cluster counts
+(one small D->H copy per pass, as in the reference :31).
+"""
+import torch
+
+from . import ops
+
+
+class SegmentationPipeline:
+    def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True):
+        from src.mean_shift import MeanShift
+        self.model_type, self.model_inst = model_type, model_inst
+        self.quantile, self.iterations, self.S, self.fit = quantile, iterations, max_segments, fit
+        self.ms = MeanShift()
+
+    @torch.no_grad()
+    def __call__(self, x6):
+        """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors."""
+        x6 = x6.float().contiguous()
+        _, log_prob, _ = self.model_type.forward_point_major(x6)
+        types = ops.row_argmax(log_prob, log_prob.shape[2])
+        emb, _, edges = self.model_inst.forward_point_major(x6)
+        X = ops.row_normalize(emb, emb.shape[2])
+        labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations)
+        out = {"labels": labels, "types": types, "bw": bw, "n_labels": n_labels, "passes": passes, "edges": edges}
+        if self.fit:
+            seg_type, seg_count = ops.segment_type_vote(labels, types, self.S, log_prob.shape[2])
+            pts = x6[:, 0:3].transpose(1, 2).contiguous()
+            nrm = x6[:, 3:6].transpose(1, 2).contiguous()
+            params, valid = ops.fit_segments(pts, nrm, seg_type, labels=labels)
+            _, seg_res = ops.residual_segments(pts, seg_type, params, valid, labels=labels, sqrt=True, per_point=False)
+            out.update(seg_type=seg_type, seg_count=seg_count, params=params, valid=valid, seg_residual=seg_res)
+        return out

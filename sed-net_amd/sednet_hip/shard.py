@@ -1,0 +1,45 @@
+"""Multi-GPU layout: clouds are independent (the reference loops over them one by one,
+generate_predictions_aug.py:213; GroupNorm and mean-shift are per cloud), so a batch shards by cloud index with no
+data-path collective. One process per GPU; the only exchange is the final gather of the per-cloud results
+(RCCL all_gather over xGMI on the GPU box, gloo in the CPU tests)."""
+import torch
+
+
+def shard_range(n_items, rank, world):
+    """contiguous block of cloud indices owned by `rank` (first `n_items % world` ranks get one extra)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+GATHER_KEYS = ("labels", "types", "params", "valid", "seg_type")
+
+
+def gather_results(out, dist, keys=GATHER_KEYS):
+    """all_gather the per-cloud result tensors of every rank (equal shard sizes) -> dict with the leading
+    dimension world * B, ordered by rank (= by global cloud index for contiguous shards)."""
+    world = dist.get_world_size()
+    res = dict(out)
+    for k in keys:
+        if k not in out:
+            continue
+        t = out[k].contiguous()
+        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(full, t)
+        res[k] = full
+    return res
+
+
+def gather_ragged(t, dist):
+    """all_gather for unequal shard sizes along dim 0 (pads to the maximum, trims after)."""
+    world = dist.get_world_size()
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)

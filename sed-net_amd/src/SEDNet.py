@@ -195,14 +195,13 @@ class SEDNet(nn.Module):
         gamma, beta = c[bn_key]
         return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend)
 
-    def forward(self, points, labels=None, compute_loss=False):
-        """SEDNet.py:292-342 -> [embedding [B,emb,N], log_prob [B,P,N], embed_loss [1], edges [B,2,N]]."""
+    def forward_point_major(self, points):
+        """points [B,6,N] -> (embedding [B,N,emb], log_prob [B,N,P], edges [B,N,2]) point-major device tensors
+        (views into kernel output buffers). This is what the batched driver consumes: no transposes."""
         if not (self.primitives and self.embedding and self.edge_module is not None and self.combine_label_prim
                 and self.late_fusion):
             raise NotImplementedError("the HIP path implements the configuration used by the SED-Net scripts "
                                       "(embedding, primitives, edge_module, combine_label_prim, late_fusion)")
-        if compute_loss:
-            raise NotImplementedError("training losses are outside the inference hot path")
         with torch.no_grad():
             c = self._prepared()
             B, _, N = points.shape
@@ -229,8 +228,15 @@ class SEDNet(nn.Module):
             x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x)
             Wt, b = c["seg2"]
             emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b)                                   # :329
-            embedding = emb.transpose(1, 2).contiguous()
-            primitives_log_prob = log_prob.transpose(1, 2).contiguous()
-            edges_pred = te[:, :, P:P + 2].transpose(1, 2).contiguous()
-            embed_loss = torch.zeros(1, device=dev)                                                    # :335
+        return emb, log_prob, te[:, :, P:P + 2]
+
+    def forward(self, points, labels=None, compute_loss=False):
+        """SEDNet.py:292-342 -> [embedding [B,emb,N], log_prob [B,P,N], embed_loss [1], edges [B,2,N]]."""
+        if compute_loss:
+            raise NotImplementedError("training losses are outside the inference hot path")
+        emb, log_prob, edges = self.forward_point_major(points)
+        embedding = emb.transpose(1, 2).contiguous()
+        primitives_log_prob = log_prob.transpose(1, 2).contiguous()
+        edges_pred = edges.transpose(1, 2).contiguous()
+        embed_loss = torch.zeros(1, device=points.device)                                              # :335
         return [embedding, primitives_log_prob, embed_loss, edges_pred]

@@ -1,0 +1,71 @@
+"""GPU: the batched end-to-end pipeline (2 forwards -> clustering -> fits) against the CPU oracle run stage by
+stage on the same inputs, plus a realistic-embedding check of the clustering+fit half."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def build(T, k, salt):
+    from src.SEDNet import SEDNet
+    from sednet_hip import synth
+    m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+               combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+    m.load_state_dict({k_: T.from_numpy(v) for k_, v in synth.closed_form_state_dict(salt).items()})
+    return m.cuda().eval()
+
+
+def test_pipeline_matches_oracle_stagewise(T):
+    from oracle import backbone, mean_shift as oms
+    from sednet_hip import synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    from src.segment_utils import seg_iou
+    B, N, k = 2, 1500, 20
+    x, _, _ = synth.batch_clouds(B, N, seed0=900)
+    pipe = SegmentationPipeline(build(T, k, 0), build(T, k, 1), quantile=0.015, iterations=20)
+    out = pipe(T.from_numpy(x).cuda())
+    labels = out["labels"].cpu().numpy()
+    types = out["types"].cpu().numpy()
+    for b in range(B):
+        _, logp, _ = backbone.sednet_forward(synth.closed_form_state_dict(0), x[b:b + 1], k)
+        assert (types[b] == np.argmax(logp[0], 0)).mean() > 0.995
+        emb, _, _ = backbone.sednet_forward(synth.closed_form_state_dict(1), x[b:b + 1], k)
+        X = emb[0].T
+        X = X / np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1e-12)
+        _, bw, olab, _ = oms.guard_mean_shift(X.astype(np.float32), 0.015, 20)
+        np.testing.assert_allclose(out["bw"][b].item(), bw, rtol=1e-3)
+        assert abs(seg_iou(labels[b], olab) - 1.0) < 1e-3            # seg-IoU within 1e-3 of the CPU path
+        assert out["n_labels"][b] == np.unique(olab).shape[0]
+    assert out["params"].shape == (B, 50, 8) and out["valid"].shape == (B, 50)
+
+
+def test_cluster_and_fit_on_realistic_segments(T):
+    """clustering + type vote + fits on embeddings that carry real segment structure (what trained weights would
+    produce): every analytic patch is recovered and fitted with ~zero residual."""
+    from sednet_hip import ops, synth
+    from src.mean_shift import MeanShift
+    N = 10000
+    p, n, l, t = synth.synthetic_cloud(4321, N)
+    nseg = int(l.max()) + 1
+    rng = np.random.default_rng(5)
+    C = rng.normal(size=(nseg, 128)); C /= np.linalg.norm(C, axis=1, keepdims=True)
+    E = C[l] + 0.01 * rng.normal(size=(N, 128))
+    X = ops.row_normalize(T.from_numpy(E.astype(np.float32)).cuda()[None], 128)
+    labels, bw, n_labels, passes = MeanShift().guard_mean_shift_batch(X, 0.015, 50)
+    assert n_labels[0] == nseg and passes[0] == 1
+    from oracle.mean_shift import canonical_labels
+    np.testing.assert_array_equal(canonical_labels(labels[0].cpu().numpy()), canonical_labels(l))
+    types = T.from_numpy(t.astype(np.int32)).cuda()[None]
+    seg_type, seg_count = ops.segment_type_vote(labels, types, 50, 6)
+    pts, nrm = T.from_numpy(p).cuda()[None], T.from_numpy(n).cuda()[None]
+    params, valid = ops.fit_segments(pts, nrm, seg_type, labels=labels)
+    assert int(valid.sum()) == nseg and int(seg_count.sum()) == N
+    _, res = ops.residual_segments(pts, seg_type, params, valid, labels=labels, sqrt=False, per_point=False)
+    assert float(res.max()) < 1e-6

@@ -1,0 +1,59 @@
+"""CPU, world_size 2, gloo: the cloud-sharding + result-gather logic of the multi-GPU path (on the GPU box the
+same code runs over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_clouds, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sed-net_amd"))
+    from sednet_hip.shard import gather_ragged, gather_results, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_clouds, rank, world)
+    # stand-in for the per-rank pipeline output: deterministic functions of the global cloud index
+    idx = torch.arange(lo, hi)
+    out = {"labels": (idx[:, None] * 7 + torch.arange(N)[None]).int(),
+           "types": (idx[:, None] + torch.arange(N)[None]).int() % 6,
+           "params": idx[:, None, None].float() + torch.zeros(hi - lo, 50, 8),
+           "valid": torch.ones(hi - lo, 50, dtype=torch.int32), "seg_type": torch.zeros(hi - lo, 50, dtype=torch.int32),
+           "bw": idx.float()}
+    if (hi - lo) * world == n_clouds:
+        res = gather_results(out, dist)
+        ok = bool((res["labels"][:, 0] == torch.arange(n_clouds).int() * 7).all()) and res["params"].shape[0] == n_clouds
+        ok = ok and bool((res["params"][:, 0, 0] == torch.arange(n_clouds).float()).all()) and res["bw"].shape[0] == hi - lo
+    else:
+        full = gather_ragged(out["labels"], dist)
+        ok = full.shape[0] == n_clouds and bool((full[:, 0] == torch.arange(n_clouds).int() * 7).all())
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)            # bench.py's max-over-ranks timing reduction
+    ok = ok and float(t) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("n_clouds", [8, 7])
+def test_shard_and_gather_world2(n_clouds):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clouds, 16, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -50,6 +50,17 @@ int sed_row_kth_f32(int B, int N, int ldD, int k, const float* D, float* kth, se
 /* indices of the k smallest per row, ascending by (value, index) -> idx [B,N,k]   src/PointNet.py:83,133 (topk) */
 int sed_row_topk_idx_f32(int B, int N, int ldD, int k, const float* D, int* idx, sed_stream_t stream);
 
+/* Fused streaming kNN (two score sweeps + short candidate lists, no N x N matrix). *overflow (device int) is set to
+ * 1 when a candidate list overflowed (masses of duplicate points): the result is then invalid and the caller falls
+ * back to sed_pairdist_* + sed_row_topk_idx_f32. k <= sed_knn_fused_max_k() (85); the xyz-normal variant k <= 42.
+ * src/PointNet.py:62-87 (knn) and :90-137 (knn_points_normals) */
+size_t sed_knn_fused_workspace_bytes(int B, int N);
+int sed_knn_fused_max_k(void);
+int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
+                      int* overflow, sed_stream_t stream);
+int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws, size_t ws_bytes,
+                         int* overflow, sed_stream_t stream);
+
 /* ---- mean-shift clustering --------------------------------------------------------------------------- */
 /* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */
 int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, float* bw, sed_stream_t stream);

@@ -1,0 +1,379 @@
+// Fused streaming kNN: pairwise scores + exact top-k without materialising the N x N matrix.
+//
+// Replaces /root/reference/src/PointNet.py:62-87 (knn) and :90-137 (knn_points_normals): the reference builds
+// B x N x N fp32 (400 MB per 10k-point cloud) and runs torch.topk over it. Here each query row makes TWO sweeps
+// over the keys, recomputing the scores (same instructions, same order => bit-identical both times):
+//   sweep 1: the keys a lane sees are split into 32 buckets per query (2 lanes x 16 accumulator registers of the
+//            32x32 MFMA tile); every bucket keeps its M smallest scores. Those 32 M values are distinct elements of
+//            the row, so their k-th smallest T (k <= 32 M) is an upper bound of the row's k-th smallest score.
+//   sweep 2: every element with score <= T (expected ~1.5 k of N) is appended to a lane-private candidate list
+//            (plain stores, no atomics); >= k of them exist by construction.
+//   finalize: one wave per query rank-sorts its short list by (score, index) and writes the k winners in order
+//            (ties -> lowest index). A list overflow (only possible with masses of duplicate points) raises a
+//            flag and the caller re-runs that batch through the exact materialised path (pairwise.hip + select.hip).
+// Work: 2 x 2 N^2 C flops on the fp32 MFMA + N * (CAP lists) bytes, instead of 2 x N^2 x 4 bytes of HBM traffic
+// and a 32-step bisection per row.
+#include "common.h"
+
+namespace {
+
+constexpr int CAPL = 96;          // candidates per lane (two lanes per query)
+
+struct Cand { uint32_t key; int idx; };
+
+// ---- feature-space metric (MFMA) --------------------------------------------------------------------------
+template <int NT, int M, int PASS>
+__global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restrict__ X, const float* __restrict__ xx,
+                                                           int N, int k, uint32_t* __restrict__ Tbuf,
+                                                           Cand* __restrict__ lists, int* __restrict__ counts,
+                                                           int* __restrict__ overflow) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+    __shared__ float xxs[2][32];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const float* xxc = xx + (size_t)cloud * N;
+    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int ntiles = (N + 31) >> 5;
+
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    const float xq = xxc[qrow_c];
+
+    f32x4 stage[NT];
+    float stage_xx = 0.f;
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+        if (tid < 32) { const int key = tile * 32 + tid; stage_xx = key < N ? xxc[key] : 0.f; }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+        if (tid < 32) xxs[buf][tid] = stage_xx;
+    };
+
+    uint32_t bm[M][16];
+    if (PASS == 1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bm[i][r] = 0xFFFFFFFFu;
+    }
+    uint32_t T = 0;
+    int cnt = 0;
+    Cand* mylist = nullptr;
+    if (PASS == 2) {
+        T = Tbuf[(size_t)cloud * N + qrow_c];
+        mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPL;
+    }
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) stage_load(tile + 1);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
+            }
+        const bool ragged = (tile == ntiles - 1) && (N & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = mfma_row(r, hi);
+            const float xk = xxs[cur][krow];
+            const float t1 = __fadd_rn(-xk, 2.0f * s[r]);        // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
+            const float dv = -__fsub_rn(t1, xq);                 // ... - xx_i ; distance = -score
+            uint32_t key = f32_sortable(dv);
+            if (ragged && tile * 32 + krow >= N) key = 0xFFFFFFFFu;
+            if (PASS == 1) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) { const uint32_t lo_ = min(bm[i][r], key); key = max(bm[i][r], key); bm[i][r] = lo_; }
+            } else {
+                if (key <= T && key != 0xFFFFFFFFu) {
+                    if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
+                    ++cnt;
+                }
+            }
+        }
+        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (PASS == 1) {
+        // k-th smallest of this query's 32 M bucket values (this lane's + the partner lane's)
+        uint32_t lo = 0, hiv = 0xFFFFFFFFu;
+        for (int it = 0; it < 32; ++it) {
+            const uint32_t mid = lo + ((hiv - lo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c += bm[i][r] <= mid ? 1 : 0;
+            c += __shfl_xor(c, 32, 64);
+            if (lo < hiv) { if (c >= k) hiv = mid; else lo = mid + 1; }
+        }
+        if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
+    } else {
+        if (qrow < N) {
+            counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
+            if (cnt > CAPL) *overflow = 1;
+        }
+    }
+}
+
+// ---- first-layer metric Dp (1 + W Dn) on xyz + normals (VALU; one thread per query) -----------------------------
+template <int M, int PASS>
+__global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restrict__ x6, int N, int k, float W,
+                                                           uint32_t* __restrict__ Tbuf, Cand* __restrict__ lists,
+                                                           int* __restrict__ counts, int* __restrict__ overflow) {
+    __shared__ float ks[2][32][8];
+    const int cloud = blockIdx.y, tid = threadIdx.x;
+    const float* xc = x6 + (size_t)cloud * 6 * N;
+    const int qi = blockIdx.x * 256 + tid;
+    const int qc = qi < N ? qi : N - 1;
+    const float p0 = xc[qc], p1 = xc[N + qc], p2 = xc[2 * N + qc];
+    const float n0 = xc[3 * N + qc], n1 = xc[4 * N + qc], n2 = xc[5 * N + qc];
+    const float xxi = __fadd_rn(__fadd_rn(__fmul_rn(p0, p0), __fmul_rn(p1, p1)), __fmul_rn(p2, p2));
+    const int ntiles = (N + 31) >> 5;
+
+    uint32_t bm[M][32];
+    if (PASS == 1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bm[i][r] = 0xFFFFFFFFu;
+    }
+    uint32_t T = 0;
+    int cnt = 0;
+    Cand* mylist = nullptr;
+    if (PASS == 2) {
+        T = Tbuf[(size_t)cloud * N + qc];
+        mylist = lists + ((size_t)cloud * N + qc) * 2 * CAPL;       // one thread owns both halves
+    }
+    auto stage = [&](int tile, int buf) {
+        if (tid < 32) {
+            int j = tile * 32 + tid;
+            const bool ok = j < N;
+            j = ok ? j : N - 1;
+            const float a0 = xc[j], a1 = xc[N + j], a2 = xc[2 * N + j];
+            ks[buf][tid][0] = a0; ks[buf][tid][1] = a1; ks[buf][tid][2] = a2;
+            ks[buf][tid][3] = xc[3 * N + j]; ks[buf][tid][4] = xc[4 * N + j]; ks[buf][tid][5] = xc[5 * N + j];
+            ks[buf][tid][6] = __fadd_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)), __fmul_rn(a2, a2));
+            ks[buf][tid][7] = ok ? 1.f : 0.f;
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int cur = tile & 1;
+        if (tile + 1 < ntiles) stage(tile + 1, cur ^ 1);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const float* kq = ks[cur][r];
+            const float dotp = fmaf(p2, kq[2], fmaf(p1, kq[1], __fmul_rn(p0, kq[0])));
+            const float dotn = fmaf(n2, kq[5], fmaf(n1, kq[4], __fmul_rn(n0, kq[3])));
+            const float dp = __fadd_rn(__fsub_rn(kq[6], 2.0f * dotp), xxi);          // (xx_j - inner) + xx_i  (:109)
+            const float dn = __fsub_rn(2.0f, 2.0f * dotn);                           // :112
+            const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));       // :115
+            uint32_t key = kq[7] != 0.f ? f32_sortable(dv) : 0xFFFFFFFFu;
+            if (PASS == 1) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) { const uint32_t lo_ = min(bm[i][r], key); key = max(bm[i][r], key); bm[i][r] = lo_; }
+            } else {
+                if (key <= T && key != 0xFFFFFFFFu) {
+                    if (cnt < 2 * CAPL) { Cand c; c.key = key; c.idx = tile * 32 + r; mylist[cnt] = c; }
+                    ++cnt;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (PASS == 1) {
+        uint32_t lo = 0, hiv = 0xFFFFFFFFu;
+        for (int it = 0; it < 32; ++it) {
+            const uint32_t mid = lo + ((hiv - lo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int r = 0; r < 32; ++r) c += bm[i][r] <= mid ? 1 : 0;
+            if (lo < hiv) { if (c >= k) hiv = mid; else lo = mid + 1; }
+        }
+        if (qi < N) Tbuf[(size_t)cloud * N + qi] = lo;
+    } else if (qi < N) {
+        counts[((size_t)cloud * N + qi) * 2] = cnt < 2 * CAPL ? cnt : 2 * CAPL;
+        counts[((size_t)cloud * N + qi) * 2 + 1] = 0;
+        if (cnt > 2 * CAPL) *overflow = 1;
+    }
+}
+
+// ---- finalize: one wave per query, rank sort of the short candidate list ------------------------------------------
+__global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restrict__ lists, const int* __restrict__ counts,
+                                                           int k, size_t rows, int* __restrict__ idx_out) {
+    __shared__ Cand cs[4][2 * CAPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t row = (size_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    int c0 = counts[row * 2], c1 = counts[row * 2 + 1];
+    c0 = c0 < CAPL * 2 ? c0 : CAPL * 2;                 // pn kernel packs everything into the first half-list pair
+    c1 = c1 < CAPL ? c1 : CAPL;
+    if (c1 > 0 && c0 > CAPL) c0 = CAPL;
+    const int C = c0 + c1;
+    const Cand* l0 = lists + row * 2 * CAPL;
+    const Cand* l1 = l0 + CAPL;
+    Cand* cw = cs[wave];
+    for (int e = lane; e < C; e += 64) cw[e] = e < c0 ? l0[e] : l1[e - c0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int* out = idx_out + row * k;
+    for (int e = lane; e < C; e += 64) {
+        const Cand me = cw[e];
+        int rank = 0;
+        for (int j = 0; j < C; ++j) {
+            const Cand o = cw[j];
+            rank += (o.key < me.key) || (o.key == me.key && o.idx < me.idx);
+        }
+        if (rank < k) out[rank] = me.idx;
+    }
+}
+
+int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 -> 1, 32 -> 2, 64 -> 3, 85 -> 4)
+
+}  // namespace
+
+extern "C" size_t sed_knn_fused_workspace_bytes(int B, int N) {
+    const size_t bn = (size_t)B * N;
+    return bn * sizeof(float) /*xx*/ + bn * sizeof(uint32_t) /*T*/ + bn * 2 * sizeof(int) /*counts*/ +
+           bn * 2 * CAPL * sizeof(Cand) + 256;
+}
+extern "C" int sed_knn_fused_max_k(void) { return 85; }
+
+// X [B,N,d] point-major (first C of d channels real) -> idx [B,N,k] int32 sorted by (distance, index).
+// *overflow (device int, zeroed here) becomes 1 if any candidate list overflowed: results are then invalid and the
+// caller must use sed_pairdist_knn_f32 + sed_row_topk_idx_f32.   Replaces src/PointNet.py:62-87.
+extern "C" int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
+                                 size_t ws_bytes, int* overflow, hipStream_t stream);
+// x6 [B,6,N] channel-major -> idx [B,N,k]; metric Dp (1 + W Dn).   Replaces src/PointNet.py:90-137.
+extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws,
+                                    size_t ws_bytes, int* overflow, hipStream_t stream);
+
+namespace {
+struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; };
+Ws carve(void* ws, int B, int N) {
+    const size_t bn = (size_t)B * N;
+    Ws w;
+    w.xx = (float*)ws;
+    w.T = (uint32_t*)(w.xx + bn);
+    w.counts = (int*)(w.T + bn);
+    w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
+    return w;
+}
+__global__ void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows, int D, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float* x = X + (size_t)i * D;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(x[c], x[c]));     // xx = sum(x ** 2)  (PointNet.py:77)
+    xx[i] = acc;
+}
+template <int NT, int M>
+void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {
+    knn_sweep_kernel<NT, M, 1><<<grid, 256, 0, s>>>(X, w.xx, N, k, w.T, w.lists, w.counts, overflow);
+    knn_sweep_kernel<NT, M, 2><<<grid, 256, 0, s>>>(X, w.xx, N, k, w.T, w.lists, w.counts, overflow);
+}
+template <int NT>
+int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {
+    switch (M) {
+        case 1: launch_sweeps<NT, 1>(grid, X, w, N, k, overflow, s); break;
+        case 2: launch_sweeps<NT, 2>(grid, X, w, N, k, overflow, s); break;
+        case 3: launch_sweeps<NT, 3>(grid, X, w, N, k, overflow, s); break;
+        case 4: launch_sweeps<NT, 4>(grid, X, w, N, k, overflow, s); break;
+        default: return SED_EUNSUPPORTED;
+    }
+    return SED_OK;
+}
+}  // namespace
+
+extern "C" int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
+                                 size_t ws_bytes, int* overflow, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || k <= 0 || k > N || !X || !idx || !ws || !overflow || C > d) return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 128 || k > 85) return SED_EUNSUPPORTED;
+    if (ws_bytes < sed_knn_fused_workspace_bytes(B, N)) return SED_EINVAL;
+    const Ws w = carve(ws, B, N);
+    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    const int rows = B * N;
+    sqnorm_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(X, w.xx, rows, d, C);
+    SED_LAUNCH_CHECK();
+    dim3 grid((N + 127) / 128, B);
+    const int M = pick_M(k);
+    int rc;
+    switch (d / 32) {
+        case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, stream); break;
+        case 2: rc = launch_nt<2>(grid, M, X, w, N, k, overflow, stream); break;
+        case 3: rc = launch_nt<3>(grid, M, X, w, N, k, overflow, stream); break;
+        default: rc = launch_nt<4>(grid, M, X, w, N, k, overflow, stream); break;
+    }
+    if (rc != SED_OK) return rc;
+    SED_LAUNCH_CHECK();
+    knn_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows, idx);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws,
+                                    size_t ws_bytes, int* overflow, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || k <= 0 || k > N || !x6 || !idx || !ws || !overflow) return SED_EINVAL;
+    if (k > 42) return SED_EUNSUPPORTED;                       // M <= 2 keeps the per-thread bucket arrays in registers
+    if (ws_bytes < sed_knn_fused_workspace_bytes(B, N)) return SED_EINVAL;
+    const Ws w = carve(ws, B, N);
+    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((N + 255) / 256, B);
+    if (pick_M(k) == 1) {
+        knn_pn_sweep_kernel<1, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+        knn_pn_sweep_kernel<1, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+    } else {
+        knn_pn_sweep_kernel<2, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+        knn_pn_sweep_kernel<2, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+    }
+    SED_LAUNCH_CHECK();
+    const size_t rows = (size_t)B * N;
+    knn_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, k, rows, idx);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

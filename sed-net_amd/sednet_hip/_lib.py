@@ -25,6 +25,10 @@ SIGNATURES = {
     "sed_pairdist_pn_f32": (c_int, [c_int, c_int, c_float, P, P, c_int, P]),
     "sed_row_kth_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P]),
     "sed_row_topk_idx_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P]),
+    "sed_knn_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "sed_knn_fused_max_k": (c_int, []),
+    "sed_knn_fused_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
+    "sed_knn_pn_fused_f32": (c_int, [c_int, c_int, c_int, c_float, P, P, P, c_size_t, P, P]),
     "sed_ms_bandwidth_finalize_f32": (c_int, [c_int, c_int, c_float, P, P, P]),
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -49,12 +49,29 @@ def _pair_ws(nb, N, device):
 # selection
 # ---------------------------------------------------------------------------------------------------
 
+FUSED_KNN = True          # streaming two-sweep kNN (knn_fused.hip); False forces the materialised exact path
+FUSED_STATS = {"fused": 0, "fallback": 0}
+
+
+def _fused_ws(B, N, device):
+    nbytes = lib.sed_knn_fused_workspace_bytes(B, N)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
+
+
 def knn_features(X, k, C=None):
     """kNN graph on point-major features X [B,N,D] (first C channels real) -> idx [B,N,k] int32,
     nearest first, self included (src/PointNet.py:62-87)."""
     B, N, D = X.shape
     C = D if C is None else C
     idx = torch.empty((B, N, k), dtype=torch.int32, device=X.device)
+    if FUSED_KNN and k <= 85 and D <= 128 and N >= 32:
+        ws, nbytes = _fused_ws(B, N, X.device)
+        flag = torch.empty((1,), dtype=torch.int32, device=X.device)
+        check(lib.sed_knn_fused_f32(B, N, D, C, k, ptr(X), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()), "knn_fused")
+        if int(flag.item()) == 0:          # one tiny D->H copy; overflow only with masses of duplicate points
+            FUSED_STATS["fused"] += 1
+            return idx
+        FUSED_STATS["fallback"] += 1
     chunks, step = _cloud_chunks(B, N)
     ws = _pair_ws(step, N, X.device)
     xx = torch.empty((step * N,), dtype=torch.float32, device=X.device)
@@ -71,6 +88,15 @@ def knn_points_normals(x6, k, W=1.0):
     B, _, N = x6.shape
     x6 = x6.contiguous().float()
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x6.device)
+    if FUSED_KNN and k <= 42 and N >= 32:
+        ws, nbytes = _fused_ws(B, N, x6.device)
+        flag = torch.empty((1,), dtype=torch.int32, device=x6.device)
+        check(lib.sed_knn_pn_fused_f32(B, N, k, float(W), ptr(x6), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()),
+              "knn_pn_fused")
+        if int(flag.item()) == 0:
+            FUSED_STATS["fused"] += 1
+            return idx
+        FUSED_STATS["fallback"] += 1
     chunks, step = _cloud_chunks(B, N)
     ws = _pair_ws(step, N, x6.device)
     for b0, b1 in chunks:

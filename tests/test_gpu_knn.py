@@ -75,3 +75,32 @@ def test_knn_duplicates_and_ragged(T):
     np.testing.assert_array_equal(got[dup], np.tile(np.r_[60, 100:107], (41, 1)))
     other = np.setdiff1d(np.arange(301), dup)
     assert (got[other] == ref[other]).mean() > 0.97
+
+
+def test_fused_knn_overflow_falls_back_to_exact_path(T):
+    """> 192 identical points overflow the streaming candidate lists; the wrapper must detect it and produce the
+    exact answer through the materialised path (ties -> lowest index)."""
+    from sednet_hip import ops
+    from src.PointNet import knn, knn_points_normals
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(1, 64, 900)).astype(np.float32)
+    x[:, :, 300:700] = x[:, :, 10:11]                               # 401 identical points
+    before = dict(ops.FUSED_STATS)
+    got = knn(dev(T, x), 8, 8)[0].cpu().numpy()
+    assert ops.FUSED_STATS["fallback"] == before["fallback"] + 1
+    dup = np.r_[10, 300:700]
+    np.testing.assert_array_equal(got[dup], np.tile(np.r_[10, 300:307], (401, 1)))
+    # and the two implementations agree on ordinary data
+    y = rng.normal(size=(2, 64, 1000)).astype(np.float32)
+    a = knn(dev(T, y), 20, 20).cpu().numpy()
+    ops.FUSED_KNN = False
+    try:
+        b = knn(dev(T, y), 20, 20).cpu().numpy()
+        p, n, _, _ = __import__("sednet_hip.synth", fromlist=["x"]).synthetic_cloud(5, 1500)
+        x6 = np.concatenate([p, n], 1).T[None]
+        c_exact = knn_points_normals(dev(T, x6), 20, 20).cpu().numpy()
+    finally:
+        ops.FUSED_KNN = True
+    np.testing.assert_array_equal(a, b)                             # same scores, same tie rule: bit-identical
+    c_fused = knn_points_normals(dev(T, x6), 20, 20).cpu().numpy()
+    np.testing.assert_array_equal(c_fused, c_exact)

@@ -129,48 +129,108 @@ __global__ __launch_bounds__(256) void compact_kernel(const int* __restrict__ fl
     if (tid == 0) count[cloud] = base;
 }
 
-// ---- 3. neighbour vote over the U x U block; one wave per unique centre --------------------------------
-__global__ __launch_bounds__(64) void centre_vote_kernel(const float* __restrict__ C, const int* __restrict__ uniq,
-                                                         const int* __restrict__ n_uniq,
-                                                         const int* __restrict__ counts, const float* __restrict__ bw,
-                                                         int N, int D, int* __restrict__ voted) {
-    extern __shared__ float cu[];
+// ---- 3. neighbour vote over the U x U block of unique centres (MFMA products, rows gathered through `uniq`) ------
+// For realistic embeddings U is a few dozen; degenerate ones (everything in one cluster) make thousands of
+// converged rows "unique", so the block is evaluated like every other N x N product here instead of with scalar dots.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void centre_vote_kernel(const float* __restrict__ C, const int* __restrict__ uniq,
+                                                             const int* __restrict__ n_uniq,
+                                                             const int* __restrict__ counts,
+                                                             const float* __restrict__ bw, int N,
+                                                             int* __restrict__ voted) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+    __shared__ int cnt_s[2][32];
+    __shared__ int idx_s[2][32];
     const int cloud = blockIdx.y;
     const int U = n_uniq[cloud];
-    if ((int)blockIdx.x >= U) return;
-    const int lane = threadIdx.x;
+    if ((int)blockIdx.x * 128 >= U) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int* uq = uniq + (size_t)cloud * N;
     const float* Cc = C + (size_t)cloud * N * D;
-    const int u = uq[blockIdx.x];
-    for (int c = lane; c < D; c += 64) cu[c] = Cc[(size_t)u * D + c];
-    __syncthreads();
+    const int* cntc = counts + (size_t)cloud * N;
+    const int qpos = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow = uq[qpos < U ? qpos : U - 1];
+    const int ntiles = (U + 31) >> 5;
     const float b = bw[cloud];
-    int best_score = -1, best_j = 0x7fffffff;
-    for (int jj = lane; jj < U; jj += 64) {
-        const int j = uq[jj];
-        const float* cj = Cc + (size_t)j * D;
-        float dot = 0.f;
-        for (int c = 0; c < D; c += 4) {
-            const f32x4 v = *(const f32x4*)(cj + c);
-            dot = fmaf(cu[c], v[0], dot);
-            dot = fmaf(cu[c + 1], v[1], dot);
-            dot = fmaf(cu[c + 2], v[2], dot);
-            dot = fmaf(cu[c + 3], v[3], dot);
-        }
-        const float dist = 2.0f - 2.0f * dot;
-        const int score = dist < b ? counts[(size_t)cloud * N + j] : 0;     // mean_shift.py:168 (b, not b^2)
-        if (score > best_score) { best_score = score; best_j = j; }          // j ascending per lane
-    }
+
+    float q[NT][16];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int os = __shfl_xor(best_score, off, 64);
-        const int oj = __shfl_xor(best_j, off, 64);
-        if (os > best_score || (os == best_score && oj < best_j)) { best_score = os; best_j = oj; }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Cc + (size_t)qrow * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    f32x4 stage[NT];
+    int stage_cnt = -1, stage_idx = 0;
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int pos = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pos < U) v = *(const f32x4*)(Cc + (size_t)uq[pos] * D + 4 * c4);
+            stage[u] = v;
+        }
+        if (tid < 32) {
+            const int pos = tile * 32 + tid;
+            stage_idx = pos < U ? uq[pos] : 0x7fffffff;
+            stage_cnt = pos < U ? cntc[stage_idx] : -1;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+        if (tid < 32) { cnt_s[buf][tid] = stage_cnt; idx_s[buf][tid] = stage_idx; }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    int best_score = -1, best_j = 0x7fffffff;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) stage_load(tile + 1);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = mfma_row(r, hi);
+            const int cnt = cnt_s[cur][kr];
+            const int j = idx_s[cur][kr];
+            const float dist = 2.0f - 2.0f * s[r];
+            const int score = cnt < 0 ? -1 : (dist < b ? cnt : 0);              // mean_shift.py:168 (b, not b^2)
+            if (score > best_score || (score == best_score && j < best_j)) { best_score = score; best_j = j; }
+        }
+        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
+    const int os = __shfl_xor(best_score, 32, 64);
+    const int oj = __shfl_xor(best_j, 32, 64);
+    if (os > best_score || (os == best_score && oj < best_j)) { best_score = os; best_j = oj; }
     // a row whose every neighbour scores 0 would argmax to column 0 in the reference; cannot happen while
     // dist(u,u) < b, kept for fidelity:
     if (best_score <= 0) best_j = 0;
-    if (lane == 0) voted[(size_t)cloud * N + best_j] = 1;
+    if (qpos < U && hi == 0) voted[(size_t)cloud * N + best_j] = 1;
 }
 
 // ---- 5. labels: argmax over the selected centres; one thread per point ---------------------------------
@@ -273,7 +333,13 @@ extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const f
     SED_LAUNCH_CHECK();
     compact_kernel<<<B, 256, 0, stream>>>(counts, N, uniq, n_uniq);
     SED_LAUNCH_CHECK();
-    centre_vote_kernel<<<dim3(N, B), 64, d * sizeof(float), stream>>>(centres, uniq, n_uniq, counts, bw, N, d, voted);
+    switch (d / 32) {
+        case 1: centre_vote_kernel<1><<<g1, 256, 0, stream>>>(centres, uniq, n_uniq, counts, bw, N, voted); break;
+        case 2: centre_vote_kernel<2><<<g1, 256, 0, stream>>>(centres, uniq, n_uniq, counts, bw, N, voted); break;
+        case 3: centre_vote_kernel<3><<<g1, 256, 0, stream>>>(centres, uniq, n_uniq, counts, bw, N, voted); break;
+        case 4: centre_vote_kernel<4><<<g1, 256, 0, stream>>>(centres, uniq, n_uniq, counts, bw, N, voted); break;
+        case 5: centre_vote_kernel<5><<<g1, 256, 0, stream>>>(centres, uniq, n_uniq, counts, bw, N, voted); break;
+    }
     SED_LAUNCH_CHECK();
     compact_kernel<<<B, 256, 0, stream>>>(voted, N, centre_ids, n_centres);
     SED_LAUNCH_CHECK();

@@ -10,9 +10,17 @@ F32 = np.float32
 
 def _topk_largest(score, k):
     """Indices of the k largest entries per row, sorted descending, ties -> lowest
-    index first (torch.topk leaves tie order unspecified; PointNet.py:83,133)."""
-    order = np.argsort(-score, axis=-1, kind="stable")
-    return order[..., :k]
+    index first (torch.topk leaves tie order unspecified; PointNet.py:83,133).
+    Large rows use argpartition + a stable sort of the k survivors (what a CPU top-k does) so that the timed CPU
+    baseline is not dominated by a full sort; ties exactly at the k-th value may then resolve differently."""
+    if score.shape[-1] <= 4096:
+        order = np.argsort(-score, axis=-1, kind="stable")
+        return order[..., :k]
+    neg = -score
+    part = np.argpartition(neg, k - 1, axis=-1)[..., :k]
+    part.sort(axis=-1)                                         # index order, so the stable sort breaks ties by index
+    vals = np.take_along_axis(neg, part, axis=-1)
+    return np.take_along_axis(part, np.argsort(vals, axis=-1, kind="stable"), axis=-1)
 
 
 def _subsample(k1, k2):
@@ -27,9 +35,12 @@ def knn_scores(x):
     i.e. score[i,j] = ((-xx[j]) - inner[i,j]) - xx[i], evaluated left to right in fp32.
     """
     x = np.asarray(x, F32)
-    inner = (F32(-2.0) * (x.T @ x)).astype(F32)
+    inner = np.ascontiguousarray(x.T) @ x              # in-place elementwise below: same fp32 operations, no temporaries
+    inner *= F32(-2.0)
     xx = np.sum(x * x, axis=0, dtype=F32)
-    return ((-xx)[None, :] - inner) - xx[:, None]
+    np.subtract((-xx)[None, :], inner, out=inner)      # (-xx_j) - inner
+    inner -= xx[:, None]                                # ... - xx_i
+    return inner
 
 
 def knn(x, k1, k2):
@@ -43,14 +54,20 @@ def knn(x, k1, k2):
 def knn_points_normals_scores(x6, normal_metric_W=1.0):
     """x6 [6,N] -> score [N,N] = -Dp*(1+W*Dn) (PointNet.py:107-128)."""
     x6 = np.asarray(x6, F32)
-    p, n = x6[0:3], x6[3:6]
-    inner = (F32(2.0) * (p.T @ p)).astype(F32)
+    p, n = np.ascontiguousarray(x6[0:3]), np.ascontiguousarray(x6[3:6])
+    dp = np.ascontiguousarray(p.T) @ p                  # in-place elementwise: same fp32 operations, no temporaries
+    dp *= F32(2.0)
     xx = np.sum(p * p, axis=0, dtype=F32)
-    dp = (xx[None, :] - inner) + xx[:, None]          # :109
-    inner_n = (F32(2.0) * (n.T @ n)).astype(F32)
-    dn = F32(2.0) - inner_n                             # :112
-    d = dp * (F32(1.0) + dn * F32(normal_metric_W))     # :115
-    return -d
+    np.subtract(xx[None, :], dp, out=dp)                # xx_j - inner
+    dp += xx[:, None]                                   # ... + xx_i              :109
+    dn = np.ascontiguousarray(n.T) @ n
+    dn *= F32(2.0)
+    np.subtract(F32(2.0), dn, out=dn)                   # :112
+    dn *= F32(normal_metric_W)
+    dn += F32(1.0)
+    dp *= dn                                            # :115
+    np.negative(dp, out=dp)
+    return dp
 
 
 def knn_points_normals(x, k1, k2, normal_metric_W=1.0):

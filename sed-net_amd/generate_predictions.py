@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Batched MI355X counterpart of /root/reference/generate_predictions_aug.py (call sequence :142-441).
+
+    python generate_predictions.py <config.yml> NoSave|Save no_multi_vote|multi_vote no_fold5drop|fold5drop \\
+           [--input 'clouds/*.npz' | --synthetic 16] [--batch 16] [--out predictions] [--hpnet]
+
+Same positional argv contract as the reference (:8, :76, :79, :85), same two models (type model `model`, instance model
+`model_inst`, :142-170) with "module."-tolerant checkpoint loading (:191-198), same test-time augmentation of the
+type model (:238-362), row-normalised embedding, guard_mean_shift(quantile 0.015, 50 iterations, x1.2 while > 49
+clusters), and the same output files `{id}_inst.txt`, `{id}_type.txt` (%d) and `{id}_edge.txt` (softmax, %0.4f, ';')
+(:424-437). What differs by design: clouds are processed B at a time on the device, the dataset loader (HDF5,
+out of scope) is replaced by .npz files or synthetic clouds, and HPNet spectral re-weighting (on in the reference,
+:58) is opt-in (`--hpnet`) because its lobpcg initialisation is random (statistical parity only).
+"""
+import argparse
+import glob
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.join(HERE, "src")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from read_config import Config                      # noqa: E402
+from sednet_hip import ops, synth                    # noqa: E402
+from src.mean_shift import MeanShift                 # noqa: E402
+from src.SEDNet import SEDNet                        # noqa: E402
+from src.segment_utils import seg_iou                # noqa: E402
+
+DROP_OUT_NUM = 2000                                  # generate_predictions_aug.py:65
+ITERATIONS, QUANTILE = 50, 0.015                     # :188-189
+
+
+def build_model(k, ckpt, salt, device, log):
+    m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+               combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+    if ckpt and os.path.exists(ckpt):
+        sd = torch.load(ckpt, map_location="cpu")
+        if list(sd.keys())[0].startswith("module."):                      # :192
+            sd = {k_[k_.find(".") + 1:]: v for k_, v in sd.items()}
+        sd = {k_: v for k_, v in sd.items() if not k_.startswith("pos_enc")}   # unused buffer of the reference
+        m.load_state_dict(sd)
+        log.info("loaded %s", ckpt)
+    else:
+        log.warning("checkpoint %r not found: using closed-form synthetic weights (salt %d)", ckpt, salt)
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in synth.closed_form_state_dict(salt).items()})
+    return m.to(device).eval()
+
+
+def type_log_prob(model, x6, multi_vote, fold5drop):
+    """Type-model log-probabilities [B,6,N] with the reference's test-time augmentation (:238-362)."""
+    pts, nrm = x6[:, 0:3], x6[:, 3:6]
+    N = x6.shape[2]
+
+    def fwd(p, n):
+        return model(torch.cat([p, n], 1), None, False)[1]
+
+    def with_drops(p, n, base):
+        total = torch.zeros_like(base)
+        for i in range(N // DROP_OUT_NUM):
+            keep = torch.ones(N, dtype=torch.bool, device=x6.device)
+            keep[i * DROP_OUT_NUM:(i + 1) * DROP_OUT_NUM] = False
+            total[:, :, keep] += fwd(p[:, :, keep].contiguous(), n[:, :, keep].contiguous())
+        return base + total
+
+    lp = fwd(pts, nrm)
+    if multi_vote and not fold5drop:                                            # :238-261
+        lp = (lp + fwd(pts * 1.15, nrm) + fwd(pts * 0.85, nrm)) / 3
+    elif fold5drop and not multi_vote:                                          # :264-304
+        lp = with_drops(pts, nrm, lp)
+    elif fold5drop and multi_vote:                                              # :307-362
+        total = None
+        for diag in ((1.0, 1.0, 1.0), (-1.0, 1.0, -1.0)):
+            R = torch.tensor(diag, device=x6.device).view(1, 3, 1)
+            p, n = pts * R, nrm * R
+            cur = with_drops(p, n, fwd(p, n))
+            total = cur if total is None else total + cur
+        lp = total
+    return lp
+
+
+def load_clouds(args):
+    if args.synthetic:
+        x, labels, types = synth.batch_clouds(args.synthetic, args.points)
+        return x, labels, types, [str(i) for i in range(args.synthetic)]
+    xs, ls, ts, ids = [], [], [], []
+    for f in sorted(glob.glob(args.input)):
+        d = np.load(f)
+        xs.append(np.concatenate([d["points"], d["normals"]], 1).T.astype(np.float32))
+        ls.append(d["labels"] if "labels" in d else None)
+        ts.append(d["primitives"] if "primitives" in d else None)
+        ids.append(os.path.splitext(os.path.basename(f))[0])
+    if not xs:
+        raise SystemExit(f"no clouds match {args.input!r}")
+    return np.stack(xs), ls, ts, ids
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("save", choices=["NoSave", "Save"])
+    ap.add_argument("vote", choices=["no_multi_vote", "multi_vote"])
+    ap.add_argument("fold", choices=["no_fold5drop", "fold5drop"])
+    ap.add_argument("--input", default="")
+    ap.add_argument("--synthetic", type=int, default=0)
+    ap.add_argument("--points", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--out", default="./predictions/results")
+    ap.add_argument("--hpnet", action="store_true")
+    args = ap.parse_args(argv)
+    if not args.input and not args.synthetic:
+        ap.error("give --input GLOB of .npz clouds (points, normals[, labels, primitives]) or --synthetic N")
+
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s:%(name)s:%(message)s")
+    log = logging.getLogger("generate_predictions")
+    config = Config(args.config)
+    os.environ.setdefault("CUDA_VISIBLE_DEVICES", config.gpu.split(",")[0])        # :9-11 (one process per GPU)
+    device = torch.device("cuda")
+    model = build_model(config.knn, config.pretrain_model_path, 0, device, log)              # :191-193
+    model_inst = build_model(config.knn, config.pretrain_model_type_path, 1, device, log)    # :196-198
+    ms = MeanShift()
+    x_all, labels_all, types_all, ids = load_clouds(args)
+    if args.save == "Save":
+        os.makedirs(args.out, exist_ok=True)
+
+    s_ious = []
+    for b0 in range(0, len(ids), args.batch):
+        x = torch.from_numpy(x_all[b0:b0 + args.batch]).to(device)
+        with torch.no_grad():
+            log_prob = type_log_prob(model, x, args.vote == "multi_vote", args.fold == "fold5drop")
+            emb, _, edges = model_inst.forward_point_major(x)                        # :227-229
+            pred_types = torch.max(log_prob, 1)[1]                                   # :365
+            if args.hpnet:
+                from src.smooth_normal_matrix import hpnet_process                   # :371-377
+                emb = hpnet_process(emb, x[:, 0:3].transpose(1, 2), x[:, 3:6].transpose(1, 2))
+            X = ops.row_normalize(emb.contiguous(), emb.shape[2])                    # :377 / :380
+            labels, bw, n_labels, passes = ms.guard_mean_shift_batch(X, QUANTILE, ITERATIONS)   # :382
+            edge_prob = torch.softmax(edges, dim=2)                                  # :435
+        labels_h, types_h, edge_h = labels.cpu().numpy(), pred_types.cpu().numpy(), edge_prob.cpu().numpy()
+        for i in range(x.shape[0]):
+            cid = ids[b0 + i]
+            msg = f"ID:{cid} | clusters {n_labels[i]} (passes {passes[i]})"
+            gt = labels_all[b0 + i] if labels_all is not None else None
+            if gt is not None:
+                s = seg_iou(labels_h[i], gt)
+                s_ious.append(s)
+                msg += f" inst_iou: {s:.4f}"
+            log.info(msg)
+            if args.save == "Save":
+                np.savetxt(os.path.join(args.out, f"{cid}_inst.txt"), labels_h[i], fmt="%d")            # :427
+                np.savetxt(os.path.join(args.out, f"{cid}_type.txt"), types_h[i], fmt="%d")             # :428
+                np.savetxt(os.path.join(args.out, f"{cid}_edge.txt"), edge_h[i], fmt="%0.4f", delimiter=";")   # :437
+    if s_ious:
+        log.info("===========> inst_iou: %s", np.mean(s_ious))                      # :441
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,116 @@
+"""GPU: the batched driver (counterpart of generate_predictions_aug.py): argv contract, config reader, TTA modes,
+output files; type predictions of every TTA mode against the oracle forward."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = """comment=""
+
+[train]
+model_path = "SEDNet_{}_lr_{}_mode_{}_k{}"
+gpu = "0"
+dataset = ""
+preload_model = True
+pretrain_model_path = "ckpts/none.pth"
+pretrain_model_type_path = "ckpts/none2.pth"
+pretrain_opti_path = ""
+normals = True
+proportion = 1.0
+num_train=16000
+num_val=2700
+num_test=2700
+num_points=10000  # default 10000
+loss_weight=100
+num_epochs = 200
+grid_size = 20
+batch_size = 4
+optim = adamW
+smooth = 0.025  # comment
+sche = "reduce"
+embed = 128
+knn = 20
+weight_decay = 0.002
+dropout = 0.2
+lr = 0.0001
+eval_T = 2000
+encoder_drop = 0.0
+lr_sch = True
+patience = 5
+mode = 15
+"""
+
+
+def test_driver_end_to_end(tmp_path):
+    import generate_predictions as gp
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(CFG)
+    out = tmp_path / "out"
+    rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--synthetic", "3", "--points", "1500",
+                  "--batch", "2", "--out", str(out)])
+    assert rc == 0
+    for i in range(3):
+        inst = np.loadtxt(out / f"{i}_inst.txt")
+        typ = np.loadtxt(out / f"{i}_type.txt")
+        edge = np.loadtxt(out / f"{i}_edge.txt", delimiter=";")
+        assert inst.shape == (1500,) and typ.shape == (1500,) and edge.shape == (1500, 2)
+        assert set(np.unique(typ)) <= set(range(6)) and inst.min() == 0
+        np.testing.assert_allclose(edge.sum(1), 1.0, atol=2e-4)
+
+
+def test_config_reader_matches_reference_keys(tmp_path):
+    from read_config import Config
+    cfg = tmp_path / "c.yml"
+    cfg.write_text(CFG)
+    c = Config(str(cfg))
+    assert c.knn == 20 and c.normals is True and c.mode == 15 and c.num_points == 10000
+    assert c.pretrain_model_path == "ckpts/none.pth" and c.smooth == 0.025 and c.sche == "reduce" and c.gpu == "0"
+    cfg.write_text(CFG.replace("knn = 20\n", ""))
+    assert Config(str(cfg)).knn == 64                       # read_config.py:80-84 default
+
+
+@pytest.mark.parametrize("vote,fold", [(True, False), (False, True), (True, True)])
+def test_tta_modes_match_oracle(vote, fold):
+    """type-model TTA (generate_predictions_aug.py:238-362) on a 4000-point cloud (drop blocks of 2000 -> two
+    2000-point sub-forwards): predicted types vs the oracle doing the same augmentation."""
+    import torch
+    import generate_predictions as gp
+    from oracle import backbone
+    from sednet_hip import synth
+    N, k = 4000, 20
+    x, _, _ = synth.batch_clouds(1, N, seed0=33)
+    params = synth.closed_form_state_dict(0)
+    from src.SEDNet import SEDNet
+    m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+               combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+    m.load_state_dict({n: torch.from_numpy(v) for n, v in params.items()})
+    m = m.cuda().eval()
+    got = gp.type_log_prob(m, torch.from_numpy(x).cuda(), vote, fold).cpu().numpy()
+
+    def ofwd(xx):
+        return backbone.sednet_forward(params, xx, k)[1]
+
+    def odrops(xx, base):
+        tot = np.zeros_like(base)
+        for i in range(N // 2000):
+            keep = np.ones(N, bool); keep[i * 2000:(i + 1) * 2000] = False
+            tot[:, :, keep] += ofwd(np.ascontiguousarray(xx[:, :, keep]))
+        return base + tot
+
+    scale = lambda s: np.concatenate([x[:, :3] * s, x[:, 3:]], 1).astype(np.float32)
+    if vote and not fold:
+        ref = (ofwd(x) + ofwd(scale(1.15)) + ofwd(scale(0.85))) / 3
+    elif fold and not vote:
+        ref = odrops(x, ofwd(x))
+    else:
+        ref = 0
+        for d in ((1, 1, 1), (-1, 1, -1)):
+            R = np.array(d * 2, np.float32).reshape(1, 6, 1)
+            xr = x * R
+            ref = ref + odrops(xr, ofwd(xr))
+    err = np.abs(got - ref)          # a kNN near-tie swap can move an isolated point by a few 1e-3
+    assert np.quantile(err, 0.999) < 3e-3 and err.max() < 3e-2
+    assert (got.argmax(1) == ref.argmax(1)).mean() > 0.995

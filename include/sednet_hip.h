@@ -128,6 +128,35 @@ int sed_residual_segments_f32(int B, int N, int S, const float* points, const in
 /* LeastSquares.lstsq for an m x 3 system (QR branch / ridge branch).   src/fitting_utils.py:36-65 */
 int sed_lstsq3_f32(int m, const float* A, const float* Y, float* x, sed_stream_t stream);
 
+/* ---- native point-cloud ops of the reference -------------------------------- */
+/* Chamfer nearest neighbours both ways: dist1/idx1 [B,n], dist2/idx2 [B,m] (squared L2, ties -> lowest index).
+ * src/chamfer_distance/chamfer_distance.cu:6-155; pybind cd.forward_cuda (chamfer_distance.cpp:180-185) */
+int sed_chamfer_fwd_f32(int B, int n, int m, const float* xyz1, const float* xyz2, float* dist1, int* idx1,
+                        float* dist2, int* idx2, sed_stream_t stream);
+/* Gradients w.r.t. both clouds, deterministic (gather, no float atomics); outputs fully overwritten.
+ * src/chamfer_distance/chamfer_distance.cu:158-205; cd.backward_cuda */
+int sed_chamfer_bwd_f32(int B, int n, int m, const float* xyz1, const float* xyz2, const float* grad_dist1,
+                        const int* idx1, const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2,
+                        sed_stream_t stream);
+/* Furthest point sampling, idx [B,m], first sample = point 0, points with |p|^2 <= 1e-3 skipped; temp_ws [B*n].
+ * pointnet2/_ext_src/src/sampling_gpu.cu:74-178, sampling.cpp:70-91 */
+int sed_furthest_point_sampling_f32(int B, int n, int m, const float* xyz, float* temp_ws, int* idx,
+                                    sed_stream_t stream);
+/* First nsample neighbours with d^2 < r^2 in index order, padded with the first hit; idx [B,m,nsample] zeroed by the
+ * caller.   pointnet2/_ext_src/src/ball_query_gpu.cu:14-49 */
+int sed_ball_query_f32(int B, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx,
+                       sed_stream_t stream);
+/* out[b,c,j,s] = points[b,c,idx[b,j,s]] (nsample = 1: gather_points).
+ * pointnet2/_ext_src/src/group_points_gpu.cu:13-42, sampling_gpu.cu:13-33 */
+int sed_group_points_f32(int B, int c, int n, int npoints, int nsample, const float* points, const int* idx, float* out,
+                         sed_stream_t stream);
+/* Three nearest known points of every unknown point.   pointnet2/_ext_src/src/interpolate_gpu.cu:14-64 */
+int sed_three_nn_f32(int B, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
+                     sed_stream_t stream);
+/* out[b,c,j] = sum_t points[b,c,idx[b,j,t]] weight[b,j,t].   pointnet2/_ext_src/src/interpolate_gpu.cu:77-109 */
+int sed_three_interpolate_f32(int B, int c, int m, int n, const float* points, const int* idx, const float* weight,
+                              float* out, sed_stream_t stream);
+
 /* ---- stage glue (keeps the batched driver on the device) ----------------------------------------------- */
 /* out[r,:dpad] = in[r,:d] / max(||in[r,:d]||, 1e-12), zero padded.   generate_predictions_aug.py:377,:380 */
 int sed_row_normalize_f32(size_t rows, int d, int dpad, const float* in, int ldi, float* out, int ldo,

@@ -48,6 +48,13 @@ SIGNATURES = {
     "sed_fit_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, c_int, P, P, P]),
     "sed_residual_segments_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "sed_lstsq3_f32": (c_int, [c_int, P, P, P, P]),
+    "sed_chamfer_fwd_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "sed_chamfer_bwd_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "sed_furthest_point_sampling_f32": (c_int, [c_int, c_int, c_int, P, P, P, P]),
+    "sed_ball_query_f32": (c_int, [c_int, c_int, c_int, c_float, c_int, P, P, P, P]),
+    "sed_group_points_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "sed_three_nn_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
+    "sed_three_interpolate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "sed_row_normalize_f32": (c_int, [c_size_t, c_int, c_int, P, c_int, P, c_int, P]),
     "sed_row_argmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, P]),
     "sed_segment_type_vote": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P]),

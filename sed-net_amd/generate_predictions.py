@@ -137,7 +137,8 @@ def main(argv=None):
             pred_types = torch.max(log_prob, 1)[1]                                   # :365
             if args.hpnet:
                 from src.smooth_normal_matrix import hpnet_process                   # :371-377
-                emb = hpnet_process(emb, x[:, 0:3].transpose(1, 2), x[:, 3:6].transpose(1, 2))
+                emb = hpnet_process(emb, x[:, 0:3].transpose(1, 2).contiguous(), x[:, 3:6].transpose(1, 2).contiguous(),
+                                    normal_smooth_w=0.5, CHUNK=1000)               # NORMAL_SMOOTH_W, CHUNK (:59, :375)
             X = ops.row_normalize(emb.contiguous(), emb.shape[2])                    # :377 / :380
             labels, bw, n_labels, passes = ms.guard_mean_shift_batch(X, QUANTILE, ITERATIONS)   # :382
             edge_prob = torch.softmax(edges, dim=2)                                  # :435

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference); the fixtures are data
 be checked anywhere. Re-run:  python tests/golden/make_golden.py
 
 Fixture names follow SURVEY.md section 8(c): F-KNN, F-E2E (incl. F-EDGE intermediates),
-F-MS (+ guard-loop case), F-FIT, F-RES, F-W.
+F-MS (+ guard-loop case), F-FIT, F-RES, F-W, F-HP (HPNet spectral step).
 """
 import os
 import sys
@@ -248,7 +248,32 @@ def gen_fit():
     save("f_fit", **out)
 
 
+
+
+# ----------------------------------------------------------------------------------------
+def gen_hpnet():
+    """F-HP: HPNet spectral step on a small cloud, fixed torch seed for lobpcg."""
+    import src.smooth_normal_matrix as snm
+    N, K, CH = 600, 16, 100
+    p, n, _, _ = synth.synthetic_cloud(90, N)
+    rng = np.random.default_rng(91)
+    feat = rng.normal(size=(1, N, K)).astype(F32)
+    P, Nn, Ft = t(p[None]), t(n[None]), t(feat)
+    A = snm.construction_affinity_matrix_normal(P, Nn, sigma=0.1, knn=50)
+    ent_feat = snm.compute_entropy(Ft, CHUNK=CH)
+    torch.manual_seed(7)
+    os.makedirs("src/normal_smooth_cache", exist_ok=True)            # the reference writes its cache relative to cwd
+    out = snm.hpnet_process(Ft, P, Nn, id=None, normal_smooth_w=0.5, CHUNK=CH)
+    torch.manual_seed(7)
+    v = torch.lobpcg(A, k=12, niter=10)[1]
+    v = v / (torch.norm(v, dim=-1, keepdim=True) + 1e-16)
+    ent_v = snm.compute_entropy(v, CHUNK=CH)
+    save("f_hpnet", p=p, n=n, feat=feat, chunk=np.int32(CH), A_rows=A[0, :40].numpy(), A_rowsum=A[0].sum(1).numpy(),
+         nnid=snm.knn_idx(P, 50)[0, :40].numpy().astype(np.int32), ent_feat=ent_feat.numpy(), ent_v=ent_v.numpy(),
+         v=v.numpy(), out=out.numpy())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit"]
+    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet"]
     for w in which:
         globals()["gen_" + w]()

@@ -114,3 +114,17 @@ def test_tta_modes_match_oracle(vote, fold):
     err = np.abs(got - ref)          # a kNN near-tie swap can move an isolated point by a few 1e-3
     assert np.quantile(err, 0.999) < 3e-3 and err.max() < 3e-2
     assert (got.argmax(1) == ref.argmax(1)).mean() > 0.995
+
+
+def test_driver_with_hpnet_stage(tmp_path):
+    """--hpnet: the reference's default spectral re-weighting (torch-on-ROCm restatement incl. torch.lobpcg) feeds a
+    140-d embedding (padded to 160) into the mean-shift kernels."""
+    import generate_predictions as gp
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(CFG)
+    out = tmp_path / "out"
+    rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--synthetic", "2", "--points", "1200",
+                  "--batch", "2", "--out", str(out), "--hpnet"])
+    assert rc == 0
+    inst = np.loadtxt(out / "1_inst.txt")
+    assert inst.shape == (1200,) and inst.min() == 0

@@ -185,6 +185,140 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restr
 }
 
 
+
+// ------------------------------------------------------------------------------------------------------------
+// D = 128 specialisation (the production width): identical mathematics, two changes that only concern data movement.
+//   * 64 keys per LDS stage (two 32-key sub-tiles per barrier): half the barriers / staging bookkeeping per MFMA;
+//   * feature <-> register map d = 4 * ((r&3) + 8(r>>2) + 4 hi) + c for register (c, r) of Q / O, which makes the
+//     second product's operand read a ds_read_b128 too (16 + 16 LDS reads per sub-tile instead of 16 + 32).
+__global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __restrict__ X,
+                                                                 float* __restrict__ newX,
+                                                                 const float* __restrict__ bw, int N, int iters) {
+    constexpr int D = 128, LDX = 132, C4 = 32, KT = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // [2][KT * LDX]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const float b = bw[cloud];
+    const float neg_half_inv_b2 = -0.5f / (b * b);
+    const int ntiles = (N + KT - 1) / KT;
+
+    float q[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 4 * mfma_row(r, hi));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c][r] = v[c];
+    }
+    f32x4 stage[8];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * KT + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(lds_dyn + buf * KT * LDX + row * LDX + 4 * c4) = stage[u];
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+
+    for (int it = 0; it < iters; ++it) {
+        f32x16 o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+        float rsum = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const bool last = (it == iters - 1) && (tile == ntiles - 1);
+            if (!last) stage_load(tile + 1 == ntiles ? 0 : tile + 1);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const float* xt = lds_dyn + cur * KT * LDX + sub * 32 * LDX;
+                const int key0 = tile * KT + sub * 32;
+                if (key0 < N) {                                   // block-uniform
+                    f32x16 s;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 xa = *(const f32x4*)(xt + li * LDX + 4 * mfma_row(r, hi));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[c][r], s);
+                    }
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dist = 2.0f - 2.0f * s[r];
+                        float a = dist * neg_half_inv_b2;
+                        a = fminf(fmaxf(a, -75.0f), 75.0f);
+                        p[r] = exp_compensated(a);
+                    }
+                    if (key0 + 32 > N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rsum += p[r];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 xb = *(const f32x4*)(xt + mfma_row(r, hi) * LDX + 4 * li);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = mfma32(xb[c], p[r], o[c]);
+                    }
+                }
+            }
+            if (!last) stage_store(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = 1.0f / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = o[c][r] * Dinv - q[c][r];
+                const float nq = q[c][r] + m;
+                q[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[c][r] = q[c][r] / nrm;
+    }
+    if (qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * D;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 v = {q[0][r], q[1][r], q[2][r], q[3][r]};
+            *(f32x4*)(out + 4 * mfma_row(r, hi)) = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
@@ -196,7 +330,18 @@ extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* b
         case 1: ms_iterate_kernel<1><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 2: ms_iterate_kernel<2><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 3: ms_iterate_kernel<3><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
-        case 4: ms_iterate_kernel<4><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
+        case 4: {
+            constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);          // 66 KiB of dynamic LDS: opt in once
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+                if (e != hipSuccess) return (int)e;
+                attr_set = true;
+            }
+            ms_iterate_d128_kernel<<<grid, block, sm, stream>>>(X, newX, bw, N, iters);
+            break;
+        }
         case 5: ms_iterate_kernel<5><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
     }
     SED_LAUNCH_CHECK();

@@ -19,14 +19,16 @@ def gather_results(out, dist, keys=GATHER_KEYS):
     """all_gather the per-cloud result tensors of every rank (equal shard sizes) -> dict with the leading
     dimension world * B, ordered by rank (= by global cloud index for contiguous shards)."""
     world = dist.get_world_size()
+    host_staged = dist.get_backend() != "nccl"        # gloo (tests): collectives on host copies
     res = dict(out)
     for k in keys:
         if k not in out:
             continue
         t = out[k].contiguous()
-        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(full, t)
-        res[k] = full
+        src = t.cpu() if (host_staged and t.is_cuda) else t
+        full = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(full, src)
+        res[k] = full.to(t.device) if host_staged else full
     return res
 
 

@@ -7,7 +7,7 @@ import torch
 
 from sednet_hip import ops
 from src.guard import guard_exp
-from src.segment_utils import to_one_hot  # noqa: F401
+from src.segment_utils import match, relaxed_iou_fast, to_one_hot  # noqa: F401
 
 EPS = float(np.finfo(np.float32).eps)
 

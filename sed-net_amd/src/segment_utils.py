@@ -30,3 +30,53 @@ def seg_iou(pred_labels, gt_labels):
     r, c = linear_sum_assignment(1.0 - iou)
     keep = inter.sum(0)[c] > 0
     return float(iou[r, c][keep].mean())
+
+
+def relaxed_iou_fast(pred, gt, max_clusters=50):
+    """segment_utils.py:609-627: pred/gt one-hot [B,N,K] -> relaxed IoU cost [B,K,K]."""
+    norms_p = torch.unsqueeze(torch.sum(pred, 1), 2)
+    norms_g = torch.unsqueeze(torch.sum(gt, 1), 1)
+    dots = pred.transpose(1, 2) @ gt
+    return dots / (norms_p + norms_g - dots + 1e-7)
+
+
+def matching_iou(matching, predicted_labels, labels):
+    """segment_utils.py:548-577."""
+    IOU = []
+    for b in range(labels.shape[0]):
+        iou_b = []
+        rows, cols = matching[b]
+        for r, c in zip(rows, cols):
+            pi, gi = predicted_labels[b] == r, labels[b] == c
+            if gi.sum() == 0 and pi.sum() == 0:
+                continue
+            iou_b.append(np.logical_and(pi, gi).sum() / (np.logical_or(pi, gi).sum() + 1e-8))
+        IOU.append(np.mean(iou_b))
+    return np.mean(IOU)
+
+
+def match(target, pred_labels):
+    """fitting_utils.py:362-376: Hungarian matching of predicted to ground-truth segments on the relaxed IoU
+    (scipy.optimize.linear_sum_assignment in place of lapsolver.solve_dense; host side, <= 50 x 50)."""
+    lo = to_one_hot(np.asarray(target)).cpu()
+    co = to_one_hot(np.asarray(pred_labels)).cpu()
+    cost = relaxed_iou_fast(co.unsqueeze(0).float(), lo.unsqueeze(0).float())
+    rids, cids = linear_sum_assignment(1.0 - cost[0].numpy())
+    return rids, cids, np.unique(target), np.unique(pred_labels)
+
+
+def SIOU_matched_segments(target, pred_labels, primitives_pred, primitives, weights=None):
+    """segment_utils.py:140-185 restated for hard labels: (segment IoU, primitive-type IoU over matched segments,
+    matching). Type ids are folded like the reference ({0,6,7} -> 9, 8 -> 2)."""
+    fold = lambda a: np.where(np.isin(a, (0, 6, 7)), 9, np.where(a == 8, 2, a))
+    primitives, primitives_pred = fold(np.asarray(primitives)), fold(np.asarray(primitives_pred))
+    rids, cids, _, _ = match(target, pred_labels)
+    s_iou = matching_iou([[rids, cids]], np.asarray(pred_labels)[None], np.asarray(target)[None])
+    hits, total = 0, 0
+    for r, c in zip(rids, cids):
+        pi, gi = pred_labels == r, target == c
+        if gi.sum() == 0 or pi.sum() == 0:
+            continue
+        total += 1
+        hits += int(np.bincount(primitives_pred[pi]).argmax() == np.bincount(primitives[gi]).argmax())
+    return s_iou, hits / max(total, 1), [[rids, cids]]

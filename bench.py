@@ -179,7 +179,7 @@ def main():
                        "clouds_per_gpu": B, "points": N, "k": args.k, "ms_iterations": args.iterations,
                        "embedding_dim": 128, "weights": "closed-form synthetic", "parallelism": f"cloud-shard x{world}",
                        "mean_shift_passes_per_cloud": float(np.mean(out["passes"])) if world == 1 else None},
-            "roofline": {"kernel": "ms_iterate_kernel<4>", "bound": "mfma", "achieved": round(ach, 2),
+            "roofline": {"kernel": "ms_iterate_d128_kernel", "bound": "mfma", "achieved": round(ach, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
                          "flops_per_launch": flops_per_cloud * float(np.mean(it_clouds))},

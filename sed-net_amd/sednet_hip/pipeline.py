@@ -26,9 +26,12 @@ class SegmentationPipeline:
     def __call__(self, x6):
         """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors."""
         x6 = x6.float().contiguous()
-        _, log_prob, _ = self.model_type.forward_point_major(x6)
+        # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
+        e0, e1 = self.model_type.encoder, self.model_inst.encoder
+        idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+        _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
         types = ops.row_argmax(log_prob, log_prob.shape[2])
-        emb, _, edges = self.model_inst.forward_point_major(x6)
+        emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
         X = ops.row_normalize(emb, emb.shape[2])
         labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations)
         out = {"labels": labels, "types": types, "bw": bw, "n_labels": n_labels, "passes": passes, "edges": edges}

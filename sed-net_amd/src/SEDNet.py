@@ -79,8 +79,13 @@ class DGCNNEncoderGn(nn.Module):
         for o in out_views:
             ops.gn_apply(ysel, ysel.shape[2], G, stats, gamma, beta, ops.ACT_LEAKY, o, slope=0.2)
 
-    def forward_point_major(self, x):
-        """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major)."""
+    def input_graph(self, x):
+        """First-layer kNN graph: depends only on the input cloud (and k, W), not on the weights, so models that
+        share k and normal_metric_W -- the type and instance models of the driver -- can share it."""
+        return ops.knn_points_normals(x.detach().float().contiguous(), self.k, self.normal_metric_W)
+
+    def forward_point_major(self, x, idx1=None):
+        """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major). idx1: optional precomputed input_graph(x)."""
         if self.mode != 5 or self.input_channels != 6:
             raise NotImplementedError("the HIP path implements mode 5 with xyz+normal input (the SED-Net configuration)")
         B, _, N = x.shape
@@ -90,7 +95,7 @@ class DGCNNEncoderGn(nn.Module):
         feats = torch.empty((B, N, 256), dtype=torch.float32, device=dev)
         x8 = torch.zeros((B, N, 8), dtype=torch.float32, device=dev)
         x8[:, :, :6] = x.transpose(1, 2)
-        idx = ops.knn_points_normals(x, k, self.normal_metric_W)
+        idx = ops.knn_points_normals(x, k, self.normal_metric_W) if idx1 is None else idx1
         x1 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
         self._edge("e1", x8, 6, idx, (x1, feats[:, :, 0:64]))
         idx = ops.knn_features(x1, k, 64)
@@ -195,9 +200,10 @@ class SEDNet(nn.Module):
         gamma, beta = c[bn_key]
         return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend)
 
-    def forward_point_major(self, points):
+    def forward_point_major(self, points, idx1=None):
         """points [B,6,N] -> (embedding [B,N,emb], log_prob [B,N,P], edges [B,N,2]) point-major device tensors
-        (views into kernel output buffers). This is what the batched driver consumes: no transposes."""
+        (views into kernel output buffers). This is what the batched driver consumes: no transposes.
+        idx1: optional first-layer graph from encoder.input_graph(points) (shared between models)."""
         if not (self.primitives and self.embedding and self.edge_module is not None and self.combine_label_prim
                 and self.late_fusion):
             raise NotImplementedError("the HIP path implements the configuration used by the SED-Net scripts "
@@ -206,7 +212,7 @@ class SEDNet(nn.Module):
             c = self._prepared()
             B, _, N = points.shape
             dev = points.device
-            x4, feats = self.encoder.forward_point_major(points)
+            x4, feats = self.encoder.forward_point_major(points, idx1)
             # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
             cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
             a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"])

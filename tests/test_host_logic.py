@@ -94,3 +94,24 @@ def test_guard_loop_quantile_schedule():
     for _ in range(4):
         ks.append(int(q * 10000)); q *= 1.2
     assert ks == [150, 180, 215, 259]
+
+
+def test_src_package_shadows_and_falls_back(tmp_path):
+    """with sed-net_amd ahead on sys.path the mirrors answer `from src.X import ...`; appending the
+    reference's src directory to src.__path__ lets every module the mirrors do not provide keep resolving there."""
+    import importlib
+    import src
+    ref_src = tmp_path / "src"
+    ref_src.mkdir()
+    (ref_src / "dataset_segments.py").write_text("ori_simple_data = 'reference loader'\n")
+    (ref_src / "mean_shift.py").write_text("MeanShift = 'reference implementation (must stay shadowed)'\n")
+    src.__path__.append(str(ref_src))
+    try:
+        ds = importlib.import_module("src.dataset_segments")
+        assert ds.ori_simple_data == "reference loader"
+        ms = importlib.import_module("src.mean_shift")
+        assert "sed-net_amd" in ms.__file__ and not isinstance(ms.MeanShift, str)
+    finally:
+        src.__path__.remove(str(ref_src))
+        import sys
+        sys.modules.pop("src.dataset_segments", None)

@@ -199,9 +199,16 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y;
+    // XCD-aware block mapping: the dispatcher places consecutive workgroup ids round-robin over the 8 XCDs (private L2s);
+    // remapping gives every XCD a contiguous range of ids = whole clouds, so the ~64 workgroups resident on an XCD
+    // stream the SAME X through its L2 instead of 8 different ones (speed only; any placement is correct).
+    const int nbx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * nbx + blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int cloud = wgid / nbx, bx = wgid - cloud * nbx;
     const float* Xc = X + (size_t)cloud * N * D;
-    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow = bx * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     const float b = bw[cloud];
     const float neg_half_inv_b2 = -0.5f / (b * b);

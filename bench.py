@@ -170,7 +170,7 @@ def main():
     if rank == 0:
         total_clouds = B * world * args.steps
         line = {
-            "metric": "point-clouds/sec (10k pts, k=20) end-to-end inference",
+            "metric": f"point-clouds/sec ({N // 1000}k pts, k={args.k}) end-to-end inference",
             "value": round(total_clouds / elapsed, 3), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -43,7 +43,6 @@ def build_model(k, ckpt, salt, device, log):
         sd = torch.load(ckpt, map_location="cpu")
         if list(sd.keys())[0].startswith("module."):                      # :192
             sd = {k_[k_.find(".") + 1:]: v for k_, v in sd.items()}
-        sd = {k_: v for k_, v in sd.items() if not k_.startswith("pos_enc")}   # unused buffer of the reference
         m.load_state_dict(sd)
         log.info("loaded %s", ckpt)
     else:

@@ -30,6 +30,16 @@ def _wt(conv, k_pad=None, cols=None):
     return Wt.contiguous(), b
 
 
+class _PositionalEncoding1D(nn.Module):
+    """State-dict stand-in for positional_encodings.PositionalEncoding1D(256), which the reference instantiates
+    (SEDNet.py:285) and never calls: its persistent `inv_freq` buffer is part of real checkpoints."""
+
+    def __init__(self, channels):
+        super().__init__()
+        channels = int(-(-channels // 2) * 2)
+        self.register_buffer("inv_freq", 1.0 / (10000 ** (torch.arange(0, channels, 2).float() / channels)))
+
+
 class DGCNNEncoderGn(nn.Module):
     def __init__(self, mode=0, input_channels=3, nn_nb=80, normal_metric_W=1.):
         super(DGCNNEncoderGn, self).__init__()
@@ -159,13 +169,17 @@ class SEDNet(nn.Module):
         self.predict_normal = predict_normal
         if predict_normal:
             raise NotImplementedError("predict_normal is off in every SED-Net script; not on the HIP path")
+        self.pos_enc = _PositionalEncoding1D(256)
         self.prim_encoding = nn.Sequential(nn.Conv1d(8, 256, 1), nn.ReLU())
         self._cache = None
 
     def load_state_dict(self, state_dict, *a, **k):
+        """Checkpoints written with or without the (unused) positional-encoding buffers both load strictly."""
         self._cache = None
         self.encoder._cache = None
-        return super().load_state_dict(state_dict, *a, **k)
+        sd = {n: v for n, v in state_dict.items() if not n.startswith("pos_enc.") or n == "pos_enc.inv_freq"}
+        sd.setdefault("pos_enc.inv_freq", self.pos_enc.inv_freq)
+        return super().load_state_dict(sd, *a, **k)
 
     def _apply(self, fn, *a, **k):        # .cuda() / .to(): drop device-side weight caches
         self._cache = None

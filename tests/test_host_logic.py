@@ -35,13 +35,17 @@ def test_closed_form_weights_match_reference_key_set():
     sd = synth.closed_form_state_dict(0)
     m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
                combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=20)
-    assert sorted(m.state_dict().keys()) == sorted(sd.keys())          # SURVEY.md section 5 key set
+    # SURVEY.md section 5 key set (+ the persistent buffer of the unused positional encoding, present in real checkpoints)
+    assert sorted(m.state_dict().keys()) == sorted(list(sd.keys()) + ["pos_enc.inv_freq"])
+    assert tuple(m.state_dict()["pos_enc.inv_freq"].shape) == (128,)
     assert sum(p.numel() for p in m.parameters()) == 1351432
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     # "module."-prefixed DataParallel checkpoints load after the reference's prefix strip (generate_predictions_aug.py:192)
     pref = {"module." + k: torch.from_numpy(v) for k, v in sd.items()}
     stripped = {k[k.find(".") + 1:]: v for k, v in pref.items()}
     m.load_state_dict(stripped, strict=True)
+    with_buf = dict(stripped, **{"pos_enc.inv_freq": torch.zeros(128), "pos_enc.cached_penc": torch.zeros(1)})
+    m.load_state_dict(with_buf, strict=True)            # checkpoints from the real positional_encodings package
     np.testing.assert_array_equal(sd["encoder.bn1.weight"], sd["encoder.conv1.1.weight"])   # aliased GroupNorm
     assert (sd["encoder.bn1.weight"] < 0).any()                        # exercises the min-over-k branch
 

@@ -66,9 +66,14 @@ class DGCNNEncoderGn(nn.Module):
         self._cache = None
 
     # -- weights in kernel layout --------------------------------------------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def _prepared(self):
+        if self._cache is not None and self._cache.get("_sig") != self._signature():
+            self._cache = None                      # parameters were replaced or modified in place
         if self._cache is None:
-            c = {}
+            c = {"_sig": self._signature()}
             for i, (conv, bn) in enumerate(((self.conv1[0], self.bn1), (self.conv2[0], self.bn2),
                                             (self.conv3[0], self.bn3)), 1):
                 W = conv.weight.detach().float().reshape(conv.weight.shape[0], -1)
@@ -186,10 +191,16 @@ class SEDNet(nn.Module):
         self.encoder._cache = None
         return super()._apply(fn, *a, **k)
 
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def _prepared(self):
+        if self._cache is not None and self._cache.get("_sig") != self._signature():
+            self._cache = None                      # parameters were replaced or modified in place
         if self._cache is None:
             gb = lambda m: (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous())
             c = {
+                "_sig": self._signature(),
                 "conv1_g": self.conv1.weight.detach().float().reshape(512, 1280).contiguous(),
                 "conv1_b": self.conv1.bias.detach().float().contiguous(),
                 "conv1_f": _wt(self.conv1, cols=(1024, 1280))[0],

@@ -62,3 +62,17 @@ def test_batch_invariance(T):
     eb = m(xb)[0]
     e1 = m(xb[1:2])[0]
     np.testing.assert_array_equal(eb[1].cpu().numpy(), e1[0].cpu().numpy())
+
+
+def test_weight_cache_follows_in_place_updates(T):
+    """the kernel-layout weight cache is invalidated when parameters change in place (optimizer steps, manual edits)."""
+    from sednet_hip import synth
+    x, _, _ = synth.batch_clouds(1, 300, seed0=5)
+    m = build(T, 20, 1)
+    xb = T.from_numpy(x).cuda()
+    e0 = m(xb)[0].clone()
+    with T.no_grad():
+        m.mlp_seg_prob2.weight.mul_(2.0)
+        m.mlp_seg_prob2.bias.mul_(2.0)
+    e1 = m(xb)[0]
+    np.testing.assert_allclose(e1.cpu().numpy(), 2.0 * e0.cpu().numpy(), rtol=1e-5, atol=1e-6)

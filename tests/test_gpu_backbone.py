@@ -76,3 +76,34 @@ def test_weight_cache_follows_in_place_updates(T):
         m.mlp_seg_prob2.bias.mul_(2.0)
     e1 = m(xb)[0]
     np.testing.assert_allclose(e1.cpu().numpy(), 2.0 * e0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties(T):
+    """BASELINE size (N = 10 000, k = 20): kNN rows checked exactly on a row sample, permutation equivariance and batch
+    invariance of the whole forward (size-independent properties; the oracle forward at this size takes ~10 s per cloud
+    and is only used on a row sample here)."""
+    from oracle import graph
+    from sednet_hip import ops, synth
+    N, k = 10000, 20
+    x, _, _ = synth.batch_clouds(2, N, seed0=1234)
+    xb = T.from_numpy(x).cuda()
+    # first-layer graph: exact check of 64 sampled rows against fp32 scores computed on the host
+    idx = ops.knn_points_normals(xb, k, 1.0).cpu().numpy()
+    rows = np.random.default_rng(0).choice(N, 64, replace=False)
+    score = graph.knn_points_normals_scores(x[0])[rows]                 # [64, N] = -distance
+    ref = np.argsort(-score, axis=1, kind="stable")[:, :k]
+    agree = (idx[0][rows] == ref).mean()
+    assert agree > 0.99, agree
+    assert (idx[0][:, 0] == np.arange(N)).mean() > 0.999                # self is the nearest neighbour
+    d = np.take_along_axis(-graph.knn_points_normals_scores(x[0])[rows], idx[0][rows], 1)
+    assert (np.diff(d, axis=1) >= -1e-6).all()                           # ascending distances
+    m = build(T, k, 1)
+    emb = m(xb)[0]
+    assert T.isfinite(emb).all()
+    # batch invariance: cloud 1 alone == cloud 1 in the batch
+    np.testing.assert_array_equal(m(xb[1:2])[0][0].cpu().numpy(), emb[1].cpu().numpy())
+    # permutation equivariance
+    perm = T.randperm(N, generator=T.Generator().manual_seed(3)).cuda()
+    emb_p = m(xb[0:1][:, :, perm])[0]
+    err = (emb_p[0] - emb[0][:, perm]).abs()
+    assert float(err.quantile(0.999)) < 2e-4 and float(err.max()) < 2e-2

@@ -145,12 +145,17 @@ def main():
         step()
     sync()
     ops.TIMERS = []                      # ms_iterate launches record (start, end) events from here on
+    pipe.stage_times = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync()
     elapsed = time.perf_counter() - t0
     timers, ops.TIMERS = ops.TIMERS, None
+    stage_ms = {}
+    for name, e0, e1 in pipe.stage_times:
+        stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1) / args.steps
+    pipe.stage_times = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -184,6 +189,7 @@ def main():
                          "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
                          "flops_per_launch": flops_per_cloud * float(np.mean(it_clouds))},
         }
+        line["stages_ms_per_step"] = {k_: round(v, 2) for k_, v in stage_ms.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

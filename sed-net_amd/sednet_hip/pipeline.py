@@ -15,7 +15,26 @@ import torch
 from . import ops
 
 
+class _StageTimer:
+    """records (stage, start event, end event) on the current stream when the pipeline's `stage_times` list is set"""
+
+    def __init__(self, sink):
+        self.sink = sink
+        if sink is not None:
+            self.last = torch.cuda.Event(enable_timing=True)
+            self.last.record()
+
+    def mark(self, name):
+        if self.sink is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.sink.append((name, self.last, e))
+            self.last = e
+
+
 class SegmentationPipeline:
+    stage_times = None            # set to a list to collect per-stage event pairs (bench.py)
+
     def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True):
         from src.mean_shift import MeanShift
         self.model_type, self.model_inst = model_type, model_inst
@@ -25,15 +44,20 @@ class SegmentationPipeline:
     @torch.no_grad()
     def __call__(self, x6):
         """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors."""
+        ev = _StageTimer(self.stage_times)
         x6 = x6.float().contiguous()
         # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
         e0, e1 = self.model_type.encoder, self.model_inst.encoder
         idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+        ev.mark("input_graph")
         _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
         types = ops.row_argmax(log_prob, log_prob.shape[2])
+        ev.mark("type_model")
         emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
         X = ops.row_normalize(emb, emb.shape[2])
+        ev.mark("instance_model")
         labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations)
+        ev.mark("mean_shift")
         out = {"labels": labels, "types": types, "bw": bw, "n_labels": n_labels, "passes": passes, "edges": edges}
         if self.fit:
             seg_type, seg_count = ops.segment_type_vote(labels, types, self.S, log_prob.shape[2])
@@ -42,4 +66,5 @@ class SegmentationPipeline:
             params, valid = ops.fit_segments(pts, nrm, seg_type, labels=labels)
             _, seg_res = ops.residual_segments(pts, seg_type, params, valid, labels=labels, sqrt=True, per_point=False)
             out.update(seg_type=seg_type, seg_count=seg_count, params=params, valid=valid, seg_residual=seg_res)
+            ev.mark("fits")
         return out

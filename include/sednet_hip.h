@@ -68,6 +68,10 @@ int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, 
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                        sed_stream_t stream);
+/* d = 128 has two kernels that differ only in the order tile contributions are summed: batched (one workgroup = 128
+ * queries, all keys) and split-key (one workgroup = 32 queries, keys split over 8 waves; for grids that would leave CUs
+ * idle, i.e. the reference script's batch of 1). 0 = choose by grid size (default), 1 = batched, 2 = split-key. */
+int sed_ms_set_variant(int variant);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
  * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */

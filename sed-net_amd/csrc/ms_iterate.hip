@@ -326,7 +326,155 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// D = 128, small grids (a single cloud = 79 workgroups of the kernel above cannot fill 256 CUs): split-key variant.
+// One workgroup = ONE 32-query block, 8 waves; wave w sweeps the 32-key tiles t = w, w + 8, ... with its own
+// wave-private LDS tile (no workgroup barrier inside the sweep) and produces a partial (O, sum) for the same 32 queries;
+// once per iteration the 8 partials are summed through LDS in fixed order w = 0..7 by every wave, so all waves hold the
+// same bit-identical new Q. Same per-tile arithmetic as the kernels above; only the order in which tile contributions
+// are added differs (tiles are grouped by wave), i.e. results agree with the batched kernel to fp32 rounding.
+__global__ __launch_bounds__(512, 2) void ms_iterate_d128_splitk_kernel(const float* __restrict__ X,
+                                                                        float* __restrict__ newX,
+                                                                        const float* __restrict__ bw, int N,
+                                                                        int iters) {
+    constexpr int D = 128, LDX = 132, NW = 8, TILE = 32 * LDX;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // [NW][32 * LDX]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = blockIdx.x * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const float b = bw[cloud];
+    const float neg_half_inv_b2 = -0.5f / (b * b);
+    const int ntiles = (N + 31) >> 5;
+    float* mine = lds_dyn + wave * TILE;
+
+    float q[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 4 * mfma_row(r, hi));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c][r] = v[c];
+    }
+
+    for (int it = 0; it < iters; ++it) {
+        f32x16 o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+        float rsum = 0.f;
+        for (int tile = wave; tile < ntiles; tile += NW) {
+            // wave-private staging: 32 rows x 128 floats = 1024 float4 = 16 per lane
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = lane + 64 * u;
+                const int row = i >> 5, c4 = i & 31;
+                const int key = tile * 32 + row;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+                *(f32x4*)(mine + row * LDX + 4 * c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 xa = *(const f32x4*)(mine + li * LDX + 4 * mfma_row(r, hi));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[c][r], s);
+            }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dist = 2.0f - 2.0f * s[r];
+                float a = dist * neg_half_inv_b2;
+                a = fminf(fmaxf(a, -75.0f), 75.0f);
+                p[r] = exp_compensated(a);
+            }
+            if (tile == ntiles - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (tile * 32 + mfma_row(r, hi) >= N) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rsum += p[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 xb = *(const f32x4*)(mine + mfma_row(r, hi) * LDX + 4 * li);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = mfma32(xb[c], p[r], o[c]);
+            }
+        }
+        // ---- combine the 8 partial (O, sum): wave w publishes O_w[query][d] (+ its row sums in the pad column)
+        __syncthreads();                                   // every wave is done reading its tile
+        rsum += xor32(rsum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 v = {o[0][r], o[1][r], o[2][r], o[3][r]};
+            *(f32x4*)(mine + li * LDX + 4 * mfma_row(r, hi)) = v;       // row = query li, cols 4*row(r,hi)..+3
+        }
+        if (hi == 0) mine[li * LDX + 128] = rsum;
+        __syncthreads();
+        float rs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+        for (int w = 0; w < NW; ++w) {
+            const float* part = lds_dyn + w * TILE + li * LDX;
+            rs += part[128];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 v = *(const f32x4*)(part + 4 * mfma_row(r, hi));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c][r] += v[c];
+            }
+        }
+        __syncthreads();                                   // partials consumed before the next sweep overwrites them
+        const float Dinv = 1.0f / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = o[c][r] * Dinv - q[c][r];
+                const float nq = q[c][r] + m;
+                q[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[c][r] = q[c][r] / nrm;
+    }
+    if (qrow < N && wave == 0) {
+        float* out = newX + ((size_t)cloud * N + qrow) * D;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 v = {q[0][r], q[1][r], q[2][r], q[3][r]};
+            *(f32x4*)(out + 4 * mfma_row(r, hi)) = v;
+        }
+    }
+}
+
+int g_ms_variant = 0;      // 0 = choose by grid size, 1 = batched kernel, 2 = split-key kernel
+
 }  // namespace
+
+extern "C" int sed_ms_set_variant(int variant) {
+    if (variant < 0 || variant > 2) return SED_EINVAL;
+    g_ms_variant = variant;
+    return SED_OK;
+}
 
 extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   hipStream_t stream) {
@@ -338,6 +486,24 @@ extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* b
         case 2: ms_iterate_kernel<2><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 3: ms_iterate_kernel<3><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 4: {
+            // few workgroups (single clouds): split the key sweep over 8 waves so that more CUs have work. Cost model
+            // (measured, 256 CUs, one resident workgroup of either kernel per CU at full speed): a split-key workgroup
+            // takes ~0.36 of a batched workgroup's time; each grid needs ceil(workgroups / 256) rounds.
+            const long rounds_b = ((long)B * ((N + 127) / 128) + 255) / 256;
+            const long rounds_k = ((long)B * ((N + 31) / 32) + 255) / 256;
+            const bool splitk = g_ms_variant == 2 || (g_ms_variant == 0 && 36 * rounds_k < 100 * rounds_b);
+            if (splitk) {
+                constexpr int smk = 8 * 32 * 132 * (int)sizeof(float);     // 132 KiB
+                static bool attr_k = false;
+                if (!attr_k) {
+                    hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_splitk_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, smk);
+                    if (e != hipSuccess) return (int)e;
+                    attr_k = true;
+                }
+                ms_iterate_d128_splitk_kernel<<<dim3((N + 31) / 32, B), 512, smk, stream>>>(X, newX, bw, N, iters);
+                break;
+            }
             constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);          // 66 KiB of dynamic LDS: opt in once
             static bool attr_set = false;
             if (!attr_set) {

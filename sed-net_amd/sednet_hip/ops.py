@@ -142,6 +142,11 @@ def ms_iterate(X, bw, iters):
     return out
 
 
+def ms_set_variant(variant):
+    """Force the d = 128 mean-shift kernel: "auto" (by grid size), "batched" or "splitk" (tests / measurements)."""
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2}[variant]), "ms_set_variant")
+
+
 def ms_nms(centres, X, bw):
     """-> labels [B,N] i32, centre_ids [B,N] i32, n_centres [B] i32, n_labels [B] i32
     (src/mean_shift.py:139-179)."""

@@ -35,8 +35,18 @@ def test_bandwidth_matches_golden_and_oracle(T, golden):
     np.testing.assert_allclose(bw140, oms.compute_bandwidth(g["X140"], 600, 0.05), rtol=2e-5)
 
 
+@pytest.fixture
+def variant(request):
+    """Force one of the two d = 128 iteration kernels for the test, restore the size-based choice after."""
+    from sednet_hip import ops
+    ops.ms_set_variant(request.param)
+    yield request.param
+    ops.ms_set_variant("auto")
+
+
+@pytest.mark.parametrize("variant", ["batched", "splitk"], indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
-def test_iterations_match_golden(T, golden, iters, key, atol):
+def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
     g = golden("f_ms")
     bw = max(float(g["bw_q05_ns800"]), 0.003)
@@ -75,6 +85,44 @@ def test_mean_shift_end_to_end(T, golden):
     _, _, bw, labels = ms.mean_shift(dev(T, g["X140"]), 600, 0.05, 50)
     np.testing.assert_allclose(float(bw), g["bw140"], rtol=2e-5)
     np.testing.assert_array_equal(canon(labels.cpu().numpy()), canon(g["labels140"]))
+
+
+def test_iteration_variants_agree_at_full_size(T):
+    """Batched and split-key kernels differ only in summation order: 10 000 points, ragged last tile, 3 clouds."""
+    from sednet_hip import ops, synth
+    Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + c, sigma=0.02, seed=40 + c)[0]
+                   for c in range(3)])
+    X = dev(T, Xs)
+    bw = ops.ms_bandwidth(X, 150, 0.003)
+    res = {}
+    try:
+        for v in ("batched", "splitk"):
+            ops.ms_set_variant(v)
+            res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
+            single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
+            np.testing.assert_array_equal(single[0], res[v][1])          # within a variant: independent of the batch
+    finally:
+        ops.ms_set_variant("auto")
+    # 50 iterations amplify the rounding differences of points still moving (the golden test allows 1e-5 too)
+    np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
+    assert np.isfinite(res["splitk"]).all()
+    one = {}
+    try:
+        for v in ("batched", "splitk"):
+            ops.ms_set_variant(v)
+            one[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()
+    finally:
+        ops.ms_set_variant("auto")
+    # one iteration against fp64 on a row sample: the batched kernel chains all 10 000 keys through one fp32
+    # accumulator (error ~ sqrt(N) eps), the split-key kernel sums 8 shorter chains
+    x64 = Xs[0].astype(np.float64)
+    rows = np.arange(0, x64.shape[0], 97)
+    b = float(bw[0])
+    p = np.exp(-0.5 * (2.0 - 2.0 * x64[rows] @ x64.T) / (b * b))
+    ref = p @ x64 / p.sum(1, keepdims=True)
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    np.testing.assert_allclose(one["splitk"][0][rows], ref, atol=3e-6)
+    np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
 
 def test_guard_loop_matches_golden(T, golden):

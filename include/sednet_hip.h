@@ -20,6 +20,7 @@
 #define SEDNET_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -89,6 +90,36 @@ size_t sed_edgeconv_partials_bytes(int B, int N, int Cout);
 int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                          const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
                          void* partials, size_t partials_bytes, sed_stream_t stream);
+/* Training forward of the same layer: additionally records jsel [B,N,Cout] u8 = the neighbour slot whose value was
+ * selected by the max over k (first one on ties; k <= 255); torch.max's backward routes the gradient there. */
+int sed_edgeconv_fwd_train_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
+                               const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel,
+                               float* stats, uint8_t* jsel, void* partials, size_t partials_bytes,
+                               sed_stream_t stream);
+
+/* ---- backward of the fused layers (training step) -------------------------------- */
+/* What torch.autograd derives for Conv -> GroupNorm -> activation [-> max over k] (src/SEDNet.py:37-45, 78-98,
+ * 300-329; train_sed_net.py:233-285 calls loss.backward()).
+ * GroupNorm(+activation) backward, reduction part: dout [B,N,ldd]; y [B,N,ldy] = pre-norm values (pointwise layers:
+ * the conv output; EdgeConv: ysel); stats from the forward; count = values per group (C/G*N, or C/G*N*k for EdgeConv).
+ * Outputs S [B,N,C] = rstd*gamma*dout*act'(z), per-cloud dgamma_b / dbeta_b [B,C], ak [B,G,2] = (alpha, kappa) such that
+ * d(pre-norm)[p,j,o] = S[p,o][j == j*] + alpha_g + kappa_g * y[p,j,o]. act: 0 none, 1 ReLU, 2 LeakyReLU(slope). */
+size_t sed_gn_bwd_partials_bytes(int B, int N, int C);
+int sed_gn_bwd_reduce_f32(int B, int N, int C, int G, double count, const float* dout, int ldd, const float* y,
+                          int ldy, const float* stats, const float* gamma, const float* beta, int act, float slope,
+                          float* S, float* dgamma_b, float* dbeta_b, float* ak, void* partials,
+                          size_t partials_bytes, sed_stream_t stream);
+/* pointwise layers: S <- dy = S + alpha_g + kappa_g * y (the two GEMMs dX = dy W, dW = dy^T X are plain library GEMMs) */
+int sed_gn_bwd_apply_f32(int B, int N, int C, int G, float* S, const float* y, int ldy, const float* ak,
+                         sed_stream_t stream);
+/* EdgeConv backward without materialising y / dy: dW1t, dW2t [C][Cout] (overwritten; deterministic) and, if dx != NULL
+ * (C = 64 layers), dx [B,N,lddx] += input gradient (fp32 atomics; caller zero-initialises). */
+size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout);
+int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
+                         const float* W1t, const float* W2t, const float* S, const uint8_t* jsel, const float* ak,
+                         float* dW1t, float* dW2t, float* dx, int lddx, void* partials, size_t partials_bytes,
+                         sed_stream_t stream);
+
 /* Point-wise conv as GEMM: Y = X Wt + bias + cbias[b]; flags 1 ReLU | 2 store Y | 4 GroupNorm partial sums |
  * 8 per-channel max/min over points. Wt [K][Coutp] zero padded (K % 32 == 0, Coutp % 64 == 0).
  * src/SEDNet.py:94 (mlp1), :303-329 (heads) */

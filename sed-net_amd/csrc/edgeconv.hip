@@ -22,14 +22,16 @@
 
 namespace {
 
-template <int CH>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
+// TRAIN additionally records which neighbour slot produced the selected extreme (first one on ties): the backward
+// pass routes the max-over-k gradient there (edgeconv_bwd.hip).
+template <int CH, bool TRAIN>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
 __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restrict__ x, int ldx,
                                                           const int* __restrict__ idx, int k,
                                                           const float* __restrict__ W1t,
                                                           const float* __restrict__ W2t, int Cout,
                                                           const float* __restrict__ sgn,
                                                           float* __restrict__ ysel, double* __restrict__ part,
-                                                          int N) {
+                                                          int N, uint8_t* __restrict__ jsel) {
     constexpr int C = 2 * CH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w1 = smem;                // [C][64]
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) vmask |= (p0 + mfma_row(r, hi) < N ? 1u : 0u) << r;
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    int jbest[TRAIN ? 2 : 1][TRAIN ? 16 : 1];
 
     float nxt[CH];
     load_row(ib[0], nxt);
@@ -109,7 +112,12 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[t][r];
-                sel[t][r] = fmaxf(sel[t][r], sg[t] * v);
+                if (TRAIN) {
+                    const float sv = sg[t] * v;
+                    if (sv > sel[t][r] || j == 0) { sel[t][r] = sv; jbest[t][r] = j; }
+                } else {
+                    sel[t][r] = fmaxf(sel[t][r], sg[t] * v);
+                }
                 const float vm = (vmask >> r) & 1u ? v : 0.f;
                 ps += vm;
                 pq = fmaf(vm, vm, pq);
@@ -125,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = p0 + mfma_row(r, hi);
-            if (row < N) ysel[((size_t)cloud * N + row) * Cout + o0 + 32 * t + li] = sg[t] * sel[t][r];
+            if (row < N) {
+                ysel[((size_t)cloud * N + row) * Cout + o0 + 32 * t + li] = sg[t] * sel[t][r];
+                if (TRAIN) jsel[((size_t)cloud * N + row) * Cout + o0 + 32 * t + li] = (uint8_t)jbest[t][r];
+            }
         }
 
     // deterministic partial statistics: wave reduce -> LDS -> thread 0
@@ -177,10 +188,9 @@ extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
 // x [B,N,ldx] point-major (C real channels, C in {6, 64}); idx [B,N,k]; W1t/W2t [C][Cout] = the
 // transposed halves of the Conv2d weight (difference part / centre part); sgn [Cout] = +1 where the
 // GroupNorm gamma >= 0 else -1. Outputs: ysel [B,N,Cout], stats [B][G][2] = (mean, rstd) over all N*k*(Cout/G).
-extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
-                                    const int* idx, const float* W1t, const float* W2t, const float* sgn, float eps,
-                                    float* ysel, float* stats, void* partials, size_t partials_bytes,
-                                    hipStream_t stream) {
+static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
+                        const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
+                        void* partials, size_t partials_bytes, uint8_t* jsel, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || !x || !idx || !W1t || !W2t || !sgn || !ysel || !stats || !partials)
         return SED_EINVAL;
     if (Cout % 64 != 0 || G <= 0 || (Cout / G) % 32 != 0 || ldx < C) return SED_EUNSUPPORTED;
@@ -190,11 +200,17 @@ extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G,
     double* part = (double*)partials;
     if (C == 6) {
         const size_t sm = 2 * 6 * 64 * sizeof(float) + 16 * sizeof(double);
-        edgeconv_kernel<3><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N);
+        if (jsel)
+            edgeconv_kernel<3, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
+        else
+            edgeconv_kernel<3, false><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, nullptr);
     } else if (C == 64) {
         if (ldx % 4 != 0) return SED_EUNSUPPORTED;
         const size_t sm = 2 * 64 * 64 * sizeof(float) + 16 * sizeof(double);
-        edgeconv_kernel<32><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N);
+        if (jsel)
+            edgeconv_kernel<32, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
+        else
+            edgeconv_kernel<32, false><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, nullptr);
     } else {
         return SED_EUNSUPPORTED;
     }
@@ -202,4 +218,22 @@ extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G,
     gn_finalize_kernel<<<B, 64, 0, stream>>>(part, nblk, Cout / 32, G, (double)(Cout / G) * N * k, eps, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;
+}
+
+extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
+                                    const int* idx, const float* W1t, const float* W2t, const float* sgn, float eps,
+                                    float* ysel, float* stats, void* partials, size_t partials_bytes,
+                                    hipStream_t stream) {
+    return edgeconv_fwd(B, N, C, Cout, k, G, x, ldx, idx, W1t, W2t, sgn, eps, ysel, stats, partials, partials_bytes,
+                        nullptr, stream);
+}
+
+// Training forward: same outputs plus jsel [B,N,Cout] u8 = neighbour slot of the selected extreme (k <= 255).
+extern "C" int sed_edgeconv_fwd_train_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
+                                          const int* idx, const float* W1t, const float* W2t, const float* sgn,
+                                          float eps, float* ysel, float* stats, uint8_t* jsel, void* partials,
+                                          size_t partials_bytes, hipStream_t stream) {
+    if (!jsel || k > 255) return SED_EINVAL;
+    return edgeconv_fwd(B, N, C, Cout, k, G, x, ldx, idx, W1t, W2t, sgn, eps, ysel, stats, partials, partials_bytes,
+                        jsel, stream);
 }

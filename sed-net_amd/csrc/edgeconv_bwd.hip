@@ -1,0 +1,423 @@
+// Backward of the fused layers (training step).
+//
+//   EdgeConv layer   out[p,o] = act( gamma_o * (y[p,j*,o] - mu_g) * rstd_g + beta_o ),  y[p,j,o] = W1_o.(x_j - x_p) + W2_o.x_p
+//   pointwise layer  out[p,o] = act( gamma_o * (y[p,o]   - mu_g) * rstd_g + beta_o ),  y = X W^T + b   (k = 1, j* = 0)
+// (reference: /root/reference/src/SEDNet.py:37-45,78-98 and :300-329, differentiated by torch.autograd there).
+//
+// With dz = dout * act'(z), dyhat = gamma * dz, and the group means over all M = (C/G) N k positions
+//   m1 = mean(dyhat), m2 = mean(dyhat * yhat)     (dyhat is non-zero only at the selected slot j*)
+// GroupNorm's backward is  dy[p,j,o] = S[p,o] [j == j*] + alpha_g + kappa_g y[p,j,o]  with
+//   S = rstd dyhat,  alpha = rstd (rstd m2 mu - m1),  kappa = -rstd^2 m2.
+// gn_bwd_reduce_kernel produces S, per-(cloud, channel) sums (-> dgamma, dbeta, alpha, kappa); pointwise layers finish
+// with gn_bwd_apply_kernel + two plain GEMMs (rocBLAS through torch.matmul on the host side); EdgeConv layers never
+// materialise y or dy: edgeconv_bwd_weight_kernel (contraction over points, lane = output channel) and
+// edgeconv_bwd_input_kernel (contraction over output channels, lane = point) each recompute y tile by tile in the
+// register layout their second GEMM needs.
+#include "common.h"
+
+namespace {
+
+constexpr int ACT_RELU = 1, ACT_LEAKY = 2;   // 0 = none
+
+// ---- S and per-(cloud, chunk, channel) partial sums of dz and dz * yhat ---------------------------------------
+// grid (C/64, B, nchunk), block 256 = 4 row lanes x 64 channels; rows [chunk*256, +256)
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, int ldd,
+                                                            const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act, float slope,
+                                                            int N, int C, int G, float* __restrict__ S,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4][64][2];
+    const int cloud = blockIdx.y, chunk = blockIdx.z;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int g = c / (C / G);
+    const float mu = stats[((size_t)cloud * G + g) * 2], rstd = stats[((size_t)cloud * G + g) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    double s1 = 0.0, s2 = 0.0;
+    const int r1 = min(N, (chunk + 1) * 256);
+    for (int row = chunk * 256 + rl; row < r1; row += 4) {
+        const size_t o = (size_t)cloud * N + row;
+        const float yh = (y[o * ldy + c] - mu) * rstd;
+        const float z = ga * yh + be;
+        float dz = dout[o * ldd + c];
+        if (act == ACT_RELU) dz = z > 0.f ? dz : 0.f;
+        else if (act == ACT_LEAKY) dz = z > 0.f ? dz : dz * slope;
+        S[o * C + c] = rstd * ga * dz;
+        s1 += (double)dz;
+        s2 += (double)(dz * yh);
+    }
+    red[rl][threadIdx.x & 63][0] = s1;
+    red[rl][threadIdx.x & 63][1] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const double a = red[0][cc][w] + red[1][cc][w] + red[2][cc][w] + red[3][cc][w];
+        part[(((size_t)cloud * gridDim.z + chunk) * C + blockIdx.x * 64 + cc) * 2 + w] = a;
+    }
+}
+
+// per cloud: dbeta_b[c] = sum_n dz, dgamma_b[c] = sum_n dz yhat; alpha/kappa per group.  grid B, block 256
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, int nchunk, int C, int G,
+                                                              double count, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              float* __restrict__ dgamma_b, float* __restrict__ dbeta_b,
+                                                              float* __restrict__ ak /*[B][G][2]*/) {
+    __shared__ double gsum[64][2];
+    const int cloud = blockIdx.x;
+    if (threadIdx.x < 64) { gsum[threadIdx.x][0] = 0.0; gsum[threadIdx.x][1] = 0.0; }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const double* pp = part + (((size_t)cloud * nchunk + ch) * C + c) * 2;
+            s1 += pp[0];
+            s2 += pp[1];
+        }
+        dbeta_b[(size_t)cloud * C + c] = (float)s1;
+        dgamma_b[(size_t)cloud * C + c] = (float)s2;
+    }
+    __syncthreads();
+    // group sums in fixed channel order (G <= 64 threads, each walks its channels)
+    if (threadIdx.x < G) {
+        const int g = threadIdx.x;
+        double m1 = 0.0, m2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            m1 += (double)gamma[c] * (double)dbeta_b[(size_t)cloud * C + c];
+            m2 += (double)gamma[c] * (double)dgamma_b[(size_t)cloud * C + c];
+        }
+        m1 /= count;
+        m2 /= count;
+        const double mu = stats[((size_t)cloud * G + g) * 2], rstd = stats[((size_t)cloud * G + g) * 2 + 1];
+        ak[((size_t)cloud * G + g) * 2] = (float)(rstd * (rstd * m2 * mu - m1));
+        ak[((size_t)cloud * G + g) * 2 + 1] = (float)(-rstd * rstd * m2);
+    }
+}
+
+// pointwise layers: dy = S + alpha_g + kappa_g y   (in place over S).  grid (ceil(N*C/4/256), B)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ S, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ ak, int N, int C, int G) {
+    const int cloud = blockIdx.y;
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C / 4;
+    if (i4 >= (size_t)N * c4n) return;
+    const int row = (int)(i4 / c4n), c = (int)(i4 % c4n) * 4;
+    const int g = c / (C / G);
+    const float a = ak[((size_t)cloud * G + g) * 2], kp = ak[((size_t)cloud * G + g) * 2 + 1];
+    const size_t o = (size_t)cloud * N + row;
+    f32x4 s = *(f32x4*)(S + o * C + c);
+    const f32x4 yy = *(const f32x4*)(y + o * ldy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = s[e] + a + kp * yy[e];
+    *(f32x4*)(S + o * C + c) = s;
+}
+
+// ---- EdgeConv: weight gradients ------------------------------------------------------------------------------
+// dW1t[c][o] = sum_{p,j} (x_j - x_p)[c] dy[p,j,o];  dW2t[c][o] = sum_p x_p[c] sum_j dy[p,j,o]
+// One wave = 32 points x one 32-channel slab; y is recomputed with the forward's instruction sequence (lane = channel),
+// dy is the B operand of the second MFMA (K = points), the A operand is the neighbour tile loaded channel-major.
+// grid (nwg, B, Cout/32); wave w of block b handles point blocks b*4+w, +4*nwg, ...
+template <int CH>
+__global__ __launch_bounds__(256, 1) void edgeconv_bwd_weight_kernel(const float* __restrict__ x, int ldx,
+                                                                     const int* __restrict__ idx, int k,
+                                                                     const float* __restrict__ W1t,
+                                                                     const float* __restrict__ W2t, int Cout, int G,
+                                                                     const float* __restrict__ S,
+                                                                     const uint8_t* __restrict__ jsel,
+                                                                     const float* __restrict__ ak,
+                                                                     float* __restrict__ part, int N) {
+    constexpr int C = 2 * CH;
+    constexpr int TC = (C + 31) / 32;
+    __shared__ float w1[C * 32], w2[C * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y, o0 = blockIdx.z * 32;
+    for (int i = tid; i < C * 32; i += 256) {
+        const int c = i >> 5, o = i & 31;
+        w1[i] = W1t[(size_t)c * Cout + o0 + o];
+        w2[i] = W2t[(size_t)c * Cout + o0 + o];
+    }
+    __syncthreads();
+    const int g = o0 / (Cout / G);
+    const float alpha = ak[((size_t)cloud * G + g) * 2], kappa = ak[((size_t)cloud * G + g) * 2 + 1];
+    const float* xb = x + (size_t)cloud * N * ldx;
+
+    f32x16 dW1[TC], dW2[TC];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW1[tc][r] = 0.f; dW2[tc][r] = 0.f; }
+
+    const int nblk = (N + 31) / 32;
+    for (int pb = blockIdx.x * 4 + wave; pb < nblk; pb += gridDim.x * 4) {
+        const int p0 = pb * 32;
+        const int p = p0 + li, pc = p < N ? p : N - 1;
+        const int* ib = idx + ((size_t)cloud * N + pc) * k;
+        float xc[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) xc[s] = xb[(size_t)pc * ldx + hi * CH + s];
+        f32x16 base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) base = mfma32(xc[s], w2[(hi * CH + s) * 32 + li], base);
+        float Sr[16], xcT[TC][16];
+        int js[16];
+        unsigned vmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = p0 + mfma_row(r, hi);
+            const bool ok = row < N;
+            vmask |= (ok ? 1u : 0u) << r;
+            const size_t o = ((size_t)cloud * N + (ok ? row : N - 1)) * Cout + o0 + li;
+            Sr[r] = ok ? S[o] : 0.f;
+            js[r] = ok ? (int)jsel[o] : -1;
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) {
+                const int c = 32 * tc + li;
+                xcT[tc][r] = (ok && c < C) ? xb[(size_t)row * ldx + c] : 0.f;
+            }
+        }
+        float dysum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dysum[r] = 0.f;
+
+        for (int j = 0; j < k; ++j) {
+            const int nb = ib[j];
+            f32x16 acc = base;
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const float d = xb[(size_t)nb * ldx + hi * CH + s] - xc[s];
+                acc = mfma32(d, w1[(hi * CH + s) * 32 + li], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float dy = (vmask >> r) & 1u ? alpha + kappa * acc[r] : 0.f;
+                dy += js[r] == j ? Sr[r] : 0.f;
+                dysum[r] += dy;
+                const int nbr = __shfl(nb, mfma_row(r, hi), 64);        // neighbour j of point p0 + row(r, hi)
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) {
+                    const int c = 32 * tc + li;
+                    const float dT = ((vmask >> r) & 1u) && c < C ? xb[(size_t)nbr * ldx + c] - xcT[tc][r] : 0.f;
+                    dW1[tc] = mfma32(dT, dy, dW1[tc]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) dW2[tc] = mfma32(xcT[tc][r], dysum[r], dW2[tc]);
+    }
+    // partials: part[cloud][wg][wave][2][C][Cout]
+    float* pw = part + ((((size_t)cloud * gridDim.x + blockIdx.x) * 4 + wave) * 2) * C * Cout;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * tc + mfma_row(r, hi);
+            if (c < C) {
+                pw[(size_t)c * Cout + o0 + li] = dW1[tc][r];
+                pw[(size_t)(C + c) * Cout + o0 + li] = dW2[tc][r];
+            }
+        }
+}
+
+// sum the weight partials in fixed order.  grid ceil(2*C*Cout/256)
+__global__ void edgeconv_bwd_weight_reduce_kernel(const float* __restrict__ part, int nslot, size_t stride, int n,
+                                                  float* __restrict__ dW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int s = 0; s < nslot; ++s) a += (double)part[(size_t)s * stride + i];
+    dW[i] = (float)a;
+}
+
+// ---- EdgeConv: input gradients -------------------------------------------------------------------------------
+// dx[nbr(p,j)] += W1^T dy[p,j];  dx[p] += sum_j (W2 - W1)^T dy[p,j].
+// lane = point; y^T = W (x_j - x_p) is computed with the MFMA operands swapped, so that dy^T (rows = channels) is
+// directly the B operand of the second MFMA (K = output channels). One workgroup = 128 points x one 32-channel output
+// slab (blockIdx.z); the slabs' contributions meet in dx through fp32 atomics, like the neighbour scatter itself
+// (torch's own index_select backward is atomic too).   grid (ceil(N/128), B, Cout/32)
+template <int CH>
+__global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float* __restrict__ x, int ldx,
+                                                                    const int* __restrict__ idx, int k,
+                                                                    const float* __restrict__ W1t,
+                                                                    const float* __restrict__ W2t, int Cout, int G,
+                                                                    const float* __restrict__ S,
+                                                                    const uint8_t* __restrict__ jsel,
+                                                                    const float* __restrict__ ak,
+                                                                    float* __restrict__ dx, int lddx, int N) {
+    constexpr int C = 2 * CH, LDW = 33, TC = C / 32;
+    __shared__ float w1[C * LDW], w2[C * LDW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y, o0 = blockIdx.z * 32;
+    for (int i = tid; i < C * 32; i += 256) {
+        const int c = i >> 5, o = i & 31;
+        w1[c * LDW + o] = W1t[(size_t)c * Cout + o0 + o];
+        w2[c * LDW + o] = W2t[(size_t)c * Cout + o0 + o];
+    }
+    __syncthreads();
+    const float* xb = x + (size_t)cloud * N * ldx;
+    float* dxb = dx + (size_t)cloud * N * lddx;
+    const int p = blockIdx.x * 128 + wave * 32 + li;
+    const bool ok = p < N;
+    const int pc = ok ? p : N - 1;
+    const int* ib = idx + ((size_t)cloud * N + pc) * k;
+    const int g = o0 / (Cout / G);
+    const float alpha = ak[((size_t)cloud * G + g) * 2], kappa = ak[((size_t)cloud * G + g) * 2 + 1];
+
+    float xc[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) xc[s] = xb[(size_t)pc * ldx + hi * CH + s];
+    f32x16 baseT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) baseT[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) baseT = mfma32(w2[(hi * CH + s) * LDW + li], xc[s], baseT);
+    float St[16], dysum[16];
+    int js[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const size_t o = ((size_t)cloud * N + pc) * Cout + o0 + mfma_row(r, hi);
+        St[r] = ok ? S[o] : 0.f;
+        js[r] = ok ? (int)jsel[o] : -1;
+        dysum[r] = 0.f;
+    }
+    f32x16 dxc[TC];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxc[tc][r] = 0.f;
+
+    for (int j = 0; j < k; ++j) {
+        const int nb = ib[j];
+        f32x16 yT = baseT;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const float d = xb[(size_t)nb * ldx + hi * CH + s] - xc[s];
+            yT = mfma32(w1[(hi * CH + s) * LDW + li], d, yT);
+        }
+        f32x16 df[TC];
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) df[tc][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float dy = ok ? alpha + kappa * yT[r] : 0.f;
+            dy += js[r] == j ? St[r] : 0.f;
+            dysum[r] += dy;
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) df[tc] = mfma32(w1[(32 * tc + li) * LDW + mfma_row(r, hi)], dy, df[tc]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    atomicAdd(dxb + (size_t)nb * lddx + 32 * tc + mfma_row(r, hi), df[tc][r]);
+                    dxc[tc][r] -= df[tc][r];
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+            dxc[tc] = mfma32(w2[(32 * tc + li) * LDW + mfma_row(r, hi)], dysum[r], dxc[tc]);
+    if (ok) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(dxb + (size_t)p * lddx + 32 * tc + mfma_row(r, hi), dxc[tc][r]);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t sed_gn_bwd_partials_bytes(int B, int N, int C) {
+    return (size_t)B * ((N + 255) / 256) * C * 2 * sizeof(double);
+}
+
+// GroupNorm(+activation) backward, reduction part. dout [B,N,ldd], y [B,N,ldy] = pre-norm values (pointwise layers: the
+// conv output; EdgeConv: the selected extreme `ysel`), stats [B,G,2] from the forward. count = values per group
+// (C/G * N for pointwise, C/G * N * k for EdgeConv). Outputs: S [B,N,C], dgamma_b / dbeta_b [B,C] (sum over B on the
+// host), ak [B,G,2] = (alpha, kappa).
+extern "C" int sed_gn_bwd_reduce_f32(int B, int N, int C, int G, double count, const float* dout, int ldd,
+                                     const float* y, int ldy, const float* stats, const float* gamma,
+                                     const float* beta, int act, float slope, float* S, float* dgamma_b,
+                                     float* dbeta_b, float* ak, void* partials, size_t partials_bytes,
+                                     hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !dout || !y || !stats || !gamma || !beta || !S || !dgamma_b || !dbeta_b || !ak || !partials)
+        return SED_EINVAL;
+    if (C % 64 != 0 || G <= 0 || G > 64 || C % G != 0 || ldd < C || ldy < C) return SED_EUNSUPPORTED;
+    if (partials_bytes < sed_gn_bwd_partials_bytes(B, N, C)) return SED_EINVAL;
+    const int nchunk = (N + 255) / 256;
+    gn_bwd_reduce_kernel<<<dim3(C / 64, B, nchunk), 256, 0, stream>>>(dout, ldd, y, ldy, stats, gamma, beta, act, slope,
+                                                                      N, C, G, S, (double*)partials);
+    SED_LAUNCH_CHECK();
+    gn_bwd_finalize_kernel<<<B, 256, 0, stream>>>((const double*)partials, nchunk, C, G, count, stats, gamma, dgamma_b,
+                                                  dbeta_b, ak);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// pointwise layers: S <- dy = S + alpha_g + kappa_g y
+extern "C" int sed_gn_bwd_apply_f32(int B, int N, int C, int G, float* S, const float* y, int ldy, const float* ak,
+                                    hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !S || !y || !ak) return SED_EINVAL;
+    if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / G) % 4 != 0 || ldy % 4 != 0) return SED_EUNSUPPORTED;
+    const size_t n4 = (size_t)N * (C / 4);
+    gn_bwd_apply_kernel<<<dim3((unsigned)((n4 + 255) / 256), B), 256, 0, stream>>>(S, y, ldy, ak, N, C, G);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+static int edgeconv_bwd_nwg(int N) {
+    const int nblk = (N + 31) / 32;
+    int nwg = (nblk + 3) / 4;
+    return nwg > 16 ? 16 : nwg;
+}
+
+extern "C" size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout) {
+    return (size_t)B * edgeconv_bwd_nwg(N) * 4 * 2 * C * Cout * sizeof(float);
+}
+
+// EdgeConv backward. Inputs as the forward plus S [B,N,Cout], jsel [B,N,Cout], ak [B,G,2] (sed_gn_bwd_reduce_f32 on
+// dout / ysel with count = Cout/G * N * k). Outputs dW1t, dW2t [C][Cout] (overwritten) and, when dx != NULL,
+// dx [B,N,lddx] accumulated with atomics (caller zero-initialises; only C = 64 layers have an input gradient).
+extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
+                                    const int* idx, const float* W1t, const float* W2t, const float* S,
+                                    const uint8_t* jsel, const float* ak, float* dW1t, float* dW2t, float* dx,
+                                    int lddx, void* partials, size_t partials_bytes, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || k <= 0 || k > 255 || !x || !idx || !W1t || !W2t || !S || !jsel || !ak || !dW1t || !dW2t ||
+        !partials)
+        return SED_EINVAL;
+    if (Cout % 32 != 0 || G <= 0 || (Cout / G) % 32 != 0 || ldx < C) return SED_EUNSUPPORTED;
+    if (partials_bytes < sed_edgeconv_bwd_partials_bytes(B, N, C, Cout)) return SED_EINVAL;
+    const int nwg = edgeconv_bwd_nwg(N);
+    float* part = (float*)partials;
+    dim3 grid(nwg, B, Cout / 32);
+    if (C == 6)
+        edgeconv_bwd_weight_kernel<3><<<grid, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, part, N);
+    else if (C == 64)
+        edgeconv_bwd_weight_kernel<32><<<grid, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, part, N);
+    else
+        return SED_EUNSUPPORTED;
+    SED_LAUNCH_CHECK();
+    // partial layout [slot][2][C][Cout]
+    const int n = C * Cout;
+    const int nslot = B * nwg * 4;
+    edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part, nslot, (size_t)2 * n, n, dW1t);
+    SED_LAUNCH_CHECK();
+    edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part + n, nslot, (size_t)2 * n, n, dW2t);
+    SED_LAUNCH_CHECK();
+    if (dx) {
+        if (C != 64 || lddx < C) return SED_EUNSUPPORTED;
+        edgeconv_bwd_input_kernel<32><<<dim3((N + 127) / 128, B, Cout / 32), 256, 0, stream>>>(
+            x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, dx, lddx, N);
+        SED_LAUNCH_CHECK();
+    }
+    return SED_OK;
+}

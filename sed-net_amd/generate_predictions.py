@@ -51,6 +51,7 @@ def build_model(k, ckpt, salt, device, log):
     return m.to(device).eval()
 
 
+@torch.no_grad()
 def type_log_prob(model, x6, multi_vote, fold5drop):
     """Type-model log-probabilities [B,6,N] with the reference's test-time augmentation (:238-362)."""
     pts, nrm = x6[:, 0:3], x6[:, 3:6]

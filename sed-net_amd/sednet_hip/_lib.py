@@ -37,6 +37,15 @@ SIGNATURES = {
     "sed_edgeconv_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_edgeconv_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P, P,
                                      P, c_size_t, P]),
+    "sed_edgeconv_fwd_train_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,
+                                           P, P, P, c_size_t, P]),
+    "sed_gn_bwd_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_gn_bwd_reduce_f32": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_double, P, c_int, P, c_int, P, P, P, c_int,
+                                      c_float, P, P, P, P, P, c_size_t, P]),
+    "sed_gn_bwd_apply_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "sed_edgeconv_bwd_partials_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sed_edgeconv_bwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P,
+                                     c_int, P, c_size_t, P]),
     "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_colext_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),

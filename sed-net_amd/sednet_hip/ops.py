@@ -188,6 +188,62 @@ def edgeconv(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
     return ysel, stats
 
 
+def edgeconv_train(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
+    """edgeconv() + jsel [B,N,Cout] u8 (slot selected by the max over k) for the backward pass."""
+    B, N, ldx = x.shape
+    k = idx.shape[2]
+    Cout = W1t.shape[1]
+    ysel = torch.empty((B, N, Cout), dtype=torch.float32, device=x.device)
+    jsel = torch.empty((B, N, Cout), dtype=torch.uint8, device=x.device)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    nb = lib.sed_edgeconv_partials_bytes(B, N, Cout)
+    part = _bytes(nb, x.device)
+    check(lib.sed_edgeconv_fwd_train_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(sgn),
+                                         float(eps), ptr(ysel), ptr(stats), ptr(jsel), ptr(part), nb, stream()),
+          "edgeconv_fwd_train")
+    return ysel, stats, jsel
+
+
+def gn_bwd_reduce(dout, y, C, G, count, stats, gamma, beta, act, slope=0.0):
+    """-> (S [B,N,C], dgamma [C], dbeta [C], ak [B,G,2]); see edgeconv_bwd.hip. dout / y are [B,N,ld] views."""
+    B, N = dout.shape[0], dout.shape[1]
+    dev = dout.device
+    S = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    dg = torch.empty((B, C), dtype=torch.float32, device=dev)
+    db = torch.empty((B, C), dtype=torch.float32, device=dev)
+    ak = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    nb = lib.sed_gn_bwd_partials_bytes(B, N, C)
+    part = _bytes(nb, dev)
+    check(lib.sed_gn_bwd_reduce_f32(B, N, C, G, float(count), _vptr(dout), dout.stride(1), _vptr(y), y.stride(1),
+                                    ptr(stats), ptr(gamma), ptr(beta), act, float(slope), ptr(S), ptr(dg), ptr(db),
+                                    ptr(ak), ptr(part), nb, stream()), "gn_bwd_reduce")
+    return S, dg.sum(0), db.sum(0), ak
+
+
+def gn_bwd_apply(S, y, C, G, ak):
+    """S <- dy = S + alpha_g + kappa_g y (pointwise layers)."""
+    B, N = S.shape[0], S.shape[1]
+    check(lib.sed_gn_bwd_apply_f32(B, N, C, G, ptr(S), _vptr(y), y.stride(1), ptr(ak), stream()), "gn_bwd_apply")
+    return S
+
+
+def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx):
+    """-> (dW1t [C,Cout], dW2t [C,Cout], dx [B,N,ldx] or None)."""
+    B, N, ldx = x.shape
+    k = idx.shape[2]
+    Cout = W1t.shape[1]
+    dev = x.device
+    dW1t = torch.empty((C, Cout), dtype=torch.float32, device=dev)
+    dW2t = torch.empty((C, Cout), dtype=torch.float32, device=dev)
+    dx = torch.zeros((B, N, ldx), dtype=torch.float32, device=dev) if need_dx else None
+    nb = lib.sed_edgeconv_bwd_partials_bytes(B, N, C, Cout)
+    part = _bytes(nb, dev)
+    check(lib.sed_edgeconv_bwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(S), ptr(jsel),
+                                   ptr(ak), ptr(dW1t), ptr(dW2t), ptr(dx) if need_dx else None, ldx, ptr(part), nb,
+                                   stream()), "edgeconv_bwd")
+    return dW1t, dW2t, dx
+
+
 def gn_apply(Y, C, G, stats, gamma, beta, act, out, slope=0.0, scale=1.0, addend=None):
     """out[..., :C] = scale * act(GN(Y[..., :C])) + addend; Y/out/addend are [B,N,ld*] views (row stride = ld)."""
     B, N = Y.shape[0], Y.shape[1]

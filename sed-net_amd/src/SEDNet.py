@@ -5,11 +5,14 @@ The torch.nn layers below are parameter containers only (so that reference check
 SURVEY.md section 5); forward() never calls them. Activations live point-major [B,N,C] on the device:
     kNN (pairwise rows + exact selection) -> fused EdgeConv (gather + conv + GroupNorm statistics + max_k)
     x3 -> mlp1 with fused GroupNorm statistics + max over N -> head GEMMs with fused statistics.
-Inference only (no autograd through the HIP kernels).
+With gradients enabled (training, train_sed_net.py:233-285) forward() runs the same kernels through the autograd
+wrappers of sednet_hip/autograd.py (fused forward + HIP backward); under torch.no_grad() it runs the inference path.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from sednet_hip import autograd as hag
 from sednet_hip import ops
 
 
@@ -125,9 +128,32 @@ class DGCNNEncoderGn(nn.Module):
         x4 = ops.colext_finalize(colext, B, N, 1024, 8, stats, gamma, beta)
         return x4, feats
 
+    def forward_point_major_train(self, x, idx1=None):
+        """Differentiable twin of forward_point_major (same kernels + recorded max-over-k slots)."""
+        if self.mode != 5 or self.input_channels != 6:
+            raise NotImplementedError("the HIP path implements mode 5 with xyz+normal input (the SED-Net configuration)")
+        B, _, N = x.shape
+        k = self.k
+        x = x.detach().float().contiguous()
+        x8 = torch.zeros((B, N, 8), dtype=torch.float32, device=x.device)
+        x8[:, :, :6] = x.transpose(1, 2)
+        idx = ops.knn_points_normals(x, k, self.normal_metric_W) if idx1 is None else idx1
+        x1 = hag.edgeconv_gn(x8, idx, self.conv1[0], self.bn1, 6)
+        idx2 = ops.knn_features(x1.detach(), k, 64)
+        x2 = hag.edgeconv_gn(x1, idx2, self.conv2[0], self.bn2, 64)
+        idx3 = ops.knn_features(x2.detach(), k, 64)
+        x3 = hag.edgeconv_gn(x2, idx3, self.conv3[0], self.bn3, 64)
+        self.last_graphs = (idx, idx2, idx3)          # the neighbour sets this step differentiated through
+        feats = torch.cat([x1, x2, x3], dim=2)
+        y = hag.conv_gn_act(feats, self.mlp1, self.bnmlp1)
+        return y.max(dim=1)[0], feats
+
     def forward(self, x):
         """SEDNet.py:78-98 -> (x4 [B,1024], x_features [B,256,N])."""
-        x4, feats = self.forward_point_major(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            x4, feats = self.forward_point_major_train(x)
+        else:
+            x4, feats = self.forward_point_major(x)
         return x4, feats.transpose(1, 2).contiguous()
 
     def load_state_dict(self, *a, **k):
@@ -261,13 +287,42 @@ class SEDNet(nn.Module):
             emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b)                                   # :329
         return emb, log_prob, te[:, :, P:P + 2]
 
+    def forward_point_major_train(self, points, idx1=None):
+        """Differentiable twin of forward_point_major: the Conv+GroupNorm+activation layers run the fused HIP forward
+        and the HIP backward (sednet_hip/autograd.py); the three thin output projections (256->6, 128->2, 8->256,
+        256->emb) are plain library GEMMs."""
+        if not (self.primitives and self.embedding and self.edge_module is not None and self.combine_label_prim
+                and self.late_fusion):
+            raise NotImplementedError("the HIP path implements the configuration used by the SED-Net scripts "
+                                      "(embedding, primitives, edge_module, combine_label_prim, late_fusion)")
+        x4, feats = self.encoder.forward_point_major_train(points, idx1)
+        Wc = self.conv1.weight.reshape(512, 1280)
+        cb = F.linear(x4, Wc[:, :1024], self.conv1.bias)                  # repeated-global part = per-cloud bias :300-303
+        a1 = hag.conv_gn_act(feats, self.conv1, self.bn1, cbias=cb, weight=Wc[:, 1024:], bias=None)
+        x_all = hag.conv_gn_act(a1, self.conv2, self.bn2)                                              # :304
+        x_type = hag.conv_gn_act(x_all, self.mlp_prim_prob1, self.bn_prim_prob1)                      # :311
+        lin = lambda t, conv: F.linear(t, conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+        type_logit = lin(x_type, self.mlp_prim_prob2)                                                  # :312
+        log_prob = F.log_softmax(type_logit, dim=2)
+        e1 = hag.conv_gn_act(x_type, self.edge_module[0], self.edge_module[1], act=ops.ACT_NONE)
+        edges = lin(e1, self.edge_module[2])                                                           # :316-317
+        xs = hag.conv_gn_act(x_all, self.mlp_seg_prob1, self.bn_seg_prob1)                            # :320
+        x = self.w_pos_enc * hag.conv_gn_act(x_type, self.asis[0], self.asis[1]) + xs                  # :322
+        pe = F.relu(lin(torch.cat([type_logit.detach(), edges.detach()], dim=2), self.prim_encoding[0]))
+        x = x + self.w_pos_enc * pe                                                                    # :326
+        return lin(x, self.mlp_seg_prob2), log_prob, edges                                             # :329
+
     def forward(self, points, labels=None, compute_loss=False):
         """SEDNet.py:292-342 -> [embedding [B,emb,N], log_prob [B,P,N], embed_loss [1], edges [B,2,N]]."""
-        if compute_loss:
-            raise NotImplementedError("training losses are outside the inference hot path")
-        emb, log_prob, edges = self.forward_point_major(points)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            emb, log_prob, edges = self.forward_point_major_train(points)
+        else:
+            emb, log_prob, edges = self.forward_point_major(points)
         embedding = emb.transpose(1, 2).contiguous()
         primitives_log_prob = log_prob.transpose(1, 2).contiguous()
         edges_pred = edges.transpose(1, 2).contiguous()
-        embed_loss = torch.zeros(1, device=points.device)                                              # :335
+        if compute_loss:
+            embed_loss = self.loss_function(embedding, labels.data.cpu().numpy())                       # :332-333
+        else:
+            embed_loss = torch.zeros(1, device=points.device)                                          # :335
         return [embedding, primitives_log_prob, embed_loss, edges_pred]

@@ -1,0 +1,93 @@
+"""Training losses on the embedding / type heads -- same names and call contract as
+/root/reference/src/segment_loss.py (EmbeddingLoss.triplet_loss :33-126, evaluate_miou :129-152,
+LabelSmoothingLoss :209-226, primitive_loss). Small device-side torch ops on sampled points; the heavy part of a
+training step is the model's forward/backward (sednet_hip/autograd.py).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class EmbeddingLoss:
+    def __init__(self, margin=1.0, if_mean_shift=False):
+        self.margin = margin
+        self.if_mean_shift = if_mean_shift
+
+    def triplet_loss(self, output, labels: np.ndarray, iterations=5):
+        """output [B,D,N] (any device), labels [B,N] numpy -> [1]. Draws from np.random in the reference's order:
+        one choice(…, n, replace=True) per (cloud, segment), then two choice(n_seg, 1) per candidate pair."""
+        max_segments = 5
+        B, _, N = output.shape
+        dev = output.device
+        out = F.normalize(output.permute(0, 2, 1), p=2, dim=2)
+        if self.if_mean_shift:
+            from src.mean_shift import MeanShift
+            ms = MeanShift()
+            out = torch.stack([ms.mean_shift(out[b], 4000, 0.015, iterations=iterations, nms=False)[0]
+                               for b in range(B)], 0)
+        picks = []
+        for i in range(B):
+            uniq = np.unique(labels[i])
+            n_s = min(N // uniq.shape[0] + 1, 30)
+            picks.append({l: np.random.choice(list(np.where(np.isin(labels[i], l))[0]), n_s, replace=True)
+                          for l in uniq})
+        total = torch.zeros(1, device=dev)
+        single = 0
+        for i in range(B):
+            keys = sorted(picks[i].keys())
+            nk = len(keys)
+            if nk == 1:
+                single += 1
+                continue
+            acc = torch.zeros(1, device=dev)
+            used = 0
+            for _ in range(min(max_segments * max_segments, nk * nk)):
+                k1 = np.random.choice(nk, 1)[0]
+                k2 = np.random.choice(nk, 1)[0]
+                if k1 == k2:
+                    continue
+                used += 1
+                a = out[i, torch.as_tensor(picks[i][keys[k1]], device=dev)]
+                b = out[i, torch.as_tensor(picks[i][keys[k2]], device=dev)]
+                d_pos = ((a[:, None] - a[None]) ** 2).sum(2)
+                d_neg = ((a[:, None] - b[None]) ** 2).sum(2)
+                viol = F.relu(d_pos - d_neg + self.margin)
+                hinge = viol.sum() - viol.trace()                    # anchor == positive on the diagonal
+                active = ((viol > 0).sum() + 1.0).float().detach()
+                acc = acc + hinge / active
+            total = total + acc / (used + 1e-8)
+        return total / (B - single + 1e-8)
+
+
+def evaluate_miou(gt_labels, pred_labels):
+    """gt [B,N] ints, pred [B,N,C] scores -> mean over clouds of the class-averaged IoU (segment_loss.py:129-152)."""
+    eps = np.finfo(np.float32).eps
+    pred = np.argmax(pred_labels, 2)
+    C = pred_labels.shape[2]
+    total = 0.0
+    for g, p in zip(gt_labels, pred):
+        iou = 0.0
+        for c in range(C):
+            inter = np.sum((g == c) & (p == c)) + eps
+            union = np.sum((g == c) | (p == c)) + eps
+            iou += inter / union
+        total += iou / C
+    return total / gt_labels.shape[0]
+
+
+def primitive_loss(pred, gt):
+    """NLL on log-probabilities: pred [B,C,N], gt [B,N]."""
+    return F.nll_loss(pred, gt)
+
+
+class LabelSmoothingLoss(torch.nn.Module):
+    """(1 - s) * NLL + s * mean_c(-log p_c) on log-probabilities [M,C] (segment_loss.py:209-226)."""
+
+    def __init__(self, smoothing=0.2):
+        super().__init__()
+        self.confidence = 1.0 - smoothing
+        self.smoothing = smoothing
+
+    def forward(self, logprobs, target):
+        nll = -logprobs.gather(dim=-1, index=target.unsqueeze(1)).squeeze(1)
+        return (self.confidence * nll + self.smoothing * (-logprobs.mean(dim=-1))).mean()

@@ -15,7 +15,6 @@ warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.join(ROOT, "sed-net_amd"))
 
 import ref_shim  # noqa: E402
 
@@ -24,7 +23,13 @@ ref_shim.install()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from sednet_hip import synth  # noqa: E402
+import importlib.util  # noqa: E402
+
+# the build's synthetic-input generator, loaded by file: putting sed-net_amd/ on sys.path would shadow the reference's
+# `src` namespace package with the build's own `src` package
+_spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "sed-net_amd", "sednet_hip", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
 
 torch.set_num_threads(8)
 F32 = np.float32
@@ -273,7 +278,51 @@ def gen_hpnet():
          v=v.numpy(), out=out.numpy())
 
 
+# ----------------------------------------------------------------------------------------
+from train_case import train_case as _train_case, grad_digest  # noqa: E402
+
+
+def gen_train():
+    """F-TRAIN: gradients of the reference model under torch.autograd, (1) for a fixed linear
+    functional of the three outputs, (2) for the training loss of train_sed_net.py:250-271 with np.random seeded."""
+    from src.segment_loss import EmbeddingLoss, LabelSmoothingLoss
+    from src.My_edge_loss import edge_cls_loss, compute_edge_embedding_loss
+
+    N, k, B = 384, 12, 2
+    x, labels, types, edges, edges_w, cot = _train_case(synth, N, B)
+    m = build_ref_model(k, salt=2)
+    m.train()
+    out = {"N": np.int32(N), "k": np.int32(k), "B": np.int32(B), "salt": np.int32(2)}
+
+    emb, logp, _, ed = m(points=t(x))
+    out["emb"], out["logp"], out["edges_pred"] = emb.detach().numpy(), logp.detach().numpy(), ed.detach().numpy()
+    L = (emb * t(cot["emb"])).sum() + (logp * t(cot["logp"])).sum() + (ed * t(cot["edges"])).sum()
+    m.zero_grad()
+    L.backward()
+    out["lin_loss"] = np.float64(L.item())
+    for key, v in grad_digest([(n_, p_.grad) for n_, p_ in m.named_parameters() if p_.grad is not None]).items():
+        out["lin/" + key] = v
+
+    Loss = EmbeddingLoss(margin=1.0)
+    smooth = LabelSmoothingLoss(smoothing=0.025)
+    m.zero_grad()
+    emb, logp, _, ed = m(points=t(x))
+    np.random.seed(11)
+    embed_loss = torch.mean(Loss.triplet_loss(emb, labels))
+    prim = t(types).clone()
+    edge_loss = edge_cls_loss(ed, t(edges), t(edges_w))
+    p_loss = smooth(logp.transpose(1, 2).contiguous().view(-1, 6), prim.contiguous().view(-1))
+    ee = compute_edge_embedding_loss(edges_pred=ed, pred_feat=emb, gt_label=t(labels), use_type=True,
+                                     primitives=prim, primitives_log_prob=logp)
+    loss = embed_loss + p_loss + edge_loss + 0.25 * ee
+    loss.backward()
+    out["loss"] = np.array([loss.item(), embed_loss.item(), p_loss.item(), edge_loss.item(), ee.item()])
+    for key, v in grad_digest([(n_, p_.grad) for n_, p_ in m.named_parameters() if p_.grad is not None]).items():
+        out["loss/" + key] = v
+    save("f_train", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet"]
+    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet", "train"]
     for w in which:
         globals()["gen_" + w]()

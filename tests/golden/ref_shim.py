@@ -102,6 +102,7 @@ def install():
 
     # CUDA placement -> CPU no-ops
     torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor            # segment_loss.py casts with .type(torch.cuda.FloatTensor)
     nn.Module.cuda = lambda self, *a, **k: self
     torch.Tensor.get_device = lambda self: "cpu"
     torch.get_device = lambda t: "cpu"

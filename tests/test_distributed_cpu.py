@@ -57,3 +57,51 @@ def test_shard_and_gather_world2(n_clouds):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sed-net_amd"))
+    from sednet_hip.shard import allreduce_gradients
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                         # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    net[3].weight.requires_grad_(False)                          # frozen parameter: not part of the reduction
+    full = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10.0
+    # reference: gradient of the mean loss over the whole batch on one process
+    ref = [torch.autograd.grad((net(full) ** 2).sum(1).mean(), [p for p in net.parameters() if p.requires_grad])]
+    net.zero_grad()
+    mine = full[rank * 4:(rank + 1) * 4]                         # this rank's shard of the batch
+    if rank == 1:
+        net[2].bias.requires_grad_(True)
+    (net(mine) ** 2).sum(1).mean().backward()
+    if rank == 0:
+        net[2].bias.grad = None                                  # a rank without a gradient for some parameter
+    allreduce_gradients(net, dist)
+    got = [p.grad for p in net.parameters() if p.requires_grad]
+    ok = all(torch.allclose(a, b, atol=1e-6) for (a, b), name in zip(zip(got, ref[0]), range(99)) if name != 3)
+    # the bias whose gradient was dropped on rank 0: average of (0, rank-1 gradient)
+    ok = ok and got[3].shape == ref[0][3].shape and bool(torch.isfinite(got[3]).all())
+    same = [torch.zeros_like(got[0]) for _ in range(world)]
+    dist.all_gather(same, got[0])
+    ok = ok and bool(torch.equal(same[0], same[1]))             # every rank ends with the same gradients
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_allreduce_gradients_world2():
+    """Data-parallel training step: shard the batch, average gradients with one all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

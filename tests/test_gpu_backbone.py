@@ -13,6 +13,14 @@ def T():
     return torch
 
 
+@pytest.fixture(autouse=True)
+def inference_mode(T):
+    """The inference path, as the reference script runs it (generate_predictions_aug.py:221: torch.no_grad()); with
+    gradients enabled forward() takes the training path (tests/test_gpu_train.py)."""
+    with T.no_grad():
+        yield
+
+
 def build(T, k, salt):
     from src.SEDNet import SEDNet
     from sednet_hip import synth

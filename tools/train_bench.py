@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Time the training step on one GPU: reference configuration batch_size = 4, 10 000 points,
+k = 64 (configs/config_SEDNet_normal.yml:30,37,46). Prints ms per step and the forward / backward split.
+    python tools/train_bench.py [B] [N] [k] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "sed-net_amd"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sednet_hip import synth  # noqa: E402
+from sednet_hip.train import train_step, training_loss  # noqa: E402
+from src.SEDNet import SEDNet  # noqa: E402
+from train_case import train_case  # noqa: E402
+
+B, N, k, steps = (int(a) for a in (sys.argv[1:] + ["4", "10000", "64", "5"][len(sys.argv) - 1:]))
+x, labels, types, edges, edges_w, _ = train_case(synth, N, B, seed0=700)
+m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+           combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+m.load_state_dict({n: torch.from_numpy(v) for n, v in synth.closed_form_state_dict(4).items()})
+m = m.cuda().train()
+opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.0)
+batch = tuple(torch.from_numpy(a).cuda() for a in (x, labels, types, edges, edges_w))
+for _ in range(2):
+    train_step(m, opt, batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    out = train_step(m, opt, batch)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+# forward-only share
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    with torch.enable_grad():
+        loss, _ = training_loss(m, *batch)
+torch.cuda.synchronize()
+fwd = (time.perf_counter() - t0) / steps * 1e3
+print(f"train step B={B} N={N} k={k}: {ms:.1f} ms/step ({B / ms * 1e3:.1f} clouds/s), forward+loss {fwd:.1f} ms, "
+      f"backward+optimizer {ms - fwd:.1f} ms, loss {out['loss']:.4f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")

@@ -248,8 +248,9 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
                                                                     const uint8_t* __restrict__ jsel,
                                                                     const float* __restrict__ ak,
                                                                     float* __restrict__ dx, int lddx, int N) {
-    constexpr int C = 2 * CH, LDW = 33, TC = C / 32;
+    constexpr int C = 2 * CH, LDW = 33, TC = C / 32, LDT = C + 1;
     __shared__ float w1[C * LDW], w2[C * LDW];
+    __shared__ float tr[4][32 * LDT];        // per-wave transpose tile: df[point][channel] -> channel-major rows
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int cloud = blockIdx.y, o0 = blockIdx.z * 32;
     for (int i = tid; i < C * 32; i += 256) {
@@ -311,26 +312,41 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
 #pragma unroll
             for (int tc = 0; tc < TC; ++tc) df[tc] = mfma32(w1[(32 * tc + li) * LDW + mfma_row(r, hi)], dy, df[tc]);
         }
-        if (ok) {
+        // scatter: transpose through LDS so that one atomic instruction covers the C consecutive channels of ONE
+        // neighbour row (a few cache lines) instead of 64 different rows
+        float* mytr = tr[wave];
 #pragma unroll
-            for (int tc = 0; tc < TC; ++tc)
+        for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    atomicAdd(dxb + (size_t)nb * lddx + 32 * tc + mfma_row(r, hi), df[tc][r]);
-                    dxc[tc][r] -= df[tc][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                mytr[li * LDT + 32 * tc + mfma_row(r, hi)] = df[tc][r];
+                dxc[tc][r] -= df[tc][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 32; ++q) {
+            const int row = __shfl(ok ? nb : -1, q, 64);
+            if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
         }
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
             dxc[tc] = mfma32(w2[(32 * tc + li) * LDW + mfma_row(r, hi)], dysum[r], dxc[tc]);
-    if (ok) {
+    {
+        float* mytr = tr[wave];
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(dxb + (size_t)p * lddx + 32 * tc + mfma_row(r, hi), dxc[tc][r]);
+            for (int r = 0; r < 16; ++r) mytr[li * LDT + 32 * tc + mfma_row(r, hi)] = dxc[tc][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 32; ++q) {
+            const int row = __shfl(ok ? p : -1, q, 64);
+            if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
+        }
     }
 }
 

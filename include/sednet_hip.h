@@ -203,6 +203,14 @@ int sed_row_argmax_f32(size_t rows, int C, const float* in, int ld, int* out, se
 int sed_segment_type_vote(int B, int N, int S, int C, const int* labels, const int* types, int* seg_type,
                           int* seg_count, sed_stream_t stream);
 
+/* ---- HPNet entropy weights ------------------------------------------------------ */
+/* src/smooth_normal_matrix.py:131-151 (compute_entropy): sum over all ordered pairs (i, j < M) of ||u_i - u_j|| (mode 0)
+ * or of H(exp(-alpha ||u_i - u_j||)), H(s) = -s log(s + 1e-7) - (1 - s) log(1 - s + 1e-7) (mode 1), u [M,ldu] already
+ * divided by the per-dimension interval. partials [sed_pair_entropy_partials(M)] doubles: the caller sums them. */
+size_t sed_pair_entropy_partials(int M);
+int sed_pair_entropy_f32(int M, int K, const float* u, int ldu, int mode, float alpha, double* partials,
+                         sed_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

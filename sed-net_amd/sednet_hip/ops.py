@@ -382,3 +382,16 @@ def segment_type_vote(labels, types, S, C=6):
     check(lib.sed_segment_type_vote(B, N, S, C, ptr(labels), ptr(types), ptr(seg_type), ptr(seg_count), stream()),
           "segment_type_vote")
     return seg_type, seg_count
+
+
+# ---------------------------------------------------------------------------------------------------
+# HPNet entropy weights
+# ---------------------------------------------------------------------------------------------------
+
+def pair_entropy_sum(u, mode, alpha=0.0):
+    """u [M,K] contiguous -> fp64 scalar tensor: sum over ordered pairs of ||u_i - u_j|| (mode 0) or of
+    H(exp(-alpha ||u_i - u_j||)) (mode 1); see pair_entropy.hip."""
+    M, K = u.shape
+    part = torch.empty((lib.sed_pair_entropy_partials(M),), dtype=torch.float64, device=u.device)
+    check(lib.sed_pair_entropy_f32(M, K, ptr(u), u.stride(0), mode, float(alpha), ptr(part), stream()), "pair_entropy")
+    return part.sum()

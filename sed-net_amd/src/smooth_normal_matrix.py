@@ -2,9 +2,10 @@
 (hpnet_process, construction_affinity_matrix_normal, compute_entropy, knn_idx, square_distance).
 
 SURVEY.md section 8 row a20 / f-1: this stage is on by default in the reference script
-(generate_predictions_aug.py:58, :371-377) but is not part of the north-star path; this first pass is a
-torch-on-ROCm restatement (dense N x N affinity, torch.lobpcg) that keeps the reference's quirks so that the stage can
-be switched on (`generate_predictions.py --hpnet`); dedicated kernels are the next step. Quirks kept on purpose:
+(generate_predictions_aug.py:58, :371-377) but is not part of the north-star path. The entropy weights -- 83 % of the
+stage's time as torch ops (two chunked N x N x K passes each) -- run as fused HIP kernels (pair_entropy.hip); the
+affinity construction and torch.lobpcg are a torch-on-ROCm restatement that keeps the reference's quirks so that the
+stage can be switched on (`generate_predictions.py --hpnet`). Quirks kept on purpose:
   * knn_idx takes topk *largest* squared distances: the "50 neighbours" are the 50 FARTHEST points (:35-39);
   * the affinity matrix is dense with 1e-12 background, so the mask in the symmetrisation is all ones (:73-90);
   * compute_entropy covers only the first ITER * CHUNK = 5 * CHUNK points but divides by N^2 (:105, :119-152);
@@ -53,31 +54,22 @@ def construction_affinity_matrix_normal(inputs_xyz, N_gt, sigma=0.1, knn=50):
 
 
 def compute_entropy(features, CHUNK=2000):
-    """:95-153. features [1,N,K] -> scalar tensor. Same coverage (first ITER*CHUNK points), same N^2 divisor; the
-    per-dimension interval max(f_i - f_j) - min(f_i - f_j) over that block is 2 (max f - min f) in closed form."""
+    """:95-153. features [1,N,K] on the device -> scalar tensor. Same coverage (first ITER*CHUNK points), same N^2
+    divisor; the per-dimension interval max(f_i - f_j) - min(f_i - f_j) over that block is 2 (max f - min f) in closed
+    form. The two chunked N x N passes (sum of distances, then the entropy of exp(-alpha d)) are one fused HIP kernel
+    each (pair_entropy.hip): no distance matrix is materialised."""
     assert features.shape[0] == 1
-    eps = 1e-7
-    feat = features[0]
+    if not features.is_cuda:
+        raise RuntimeError("compute_entropy runs on the HIP path: pass device tensors")
+    from sednet_hip import ops
+    feat = features[0].float()
     N, K = feat.shape
     sub = feat[:ITER * CHUNK]
     interval = 2 * (sub.max(0)[0] - sub.min(0)[0])
-    u = sub / interval
-    total = 0.0
-    blocks = [u[i * CHUNK:(i + 1) * CHUNK] for i in range(ITER) if i * CHUNK < u.shape[0]]
-    dsts = {}
-    for i, a in enumerate(blocks):
-        for j, b in enumerate(blocks):
-            d = torch.norm(a[:, None, :] - b[None, :, :], dim=2) if a.shape[0] * b.shape[0] * K <= (1 << 24) \
-                else torch.cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist")
-            dsts[(i, j)] = d
-            total = total + torch.sum(d)
-    average_dst = total / (N * N)
-    alpha = -np.log(0.5) / average_dst
-    E = 0.0
-    for d in dsts.values():
-        s = torch.exp(-alpha * d)
-        E = E + torch.sum(-s * torch.log(s + eps) - (1 - s) * torch.log(1 - s + eps))
-    return E / (N * N)
+    u = (sub / interval).contiguous()
+    average_dst = ops.pair_entropy_sum(u, 0) / (N * N)
+    alpha = -np.log(0.5) / float(average_dst)
+    return (ops.pair_entropy_sum(u, 1, alpha) / (N * N)).float()
 
 
 def hpnet_process(affinity_feat, inputs_xyz, normals, id=None, types=None, edges=None, normal_smooth_w=0.5, CHUNK=2000,

@@ -1,0 +1,62 @@
+"""GPU: HPNet spectral step on the device -- fused entropy kernels (pair_entropy.hip)
++ torch-on-ROCm affinity / lobpcg -- against golden data captured from the reference (deterministic parts exactly; the
+lobpcg eigenvectors statistically) and against the numpy oracle at other sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return torch
+
+
+def test_mirror_matches_reference(T, golden):
+    from src import smooth_normal_matrix as snm
+    g = golden("f_hpnet")
+    torch = T
+    P, Nn, Ft = (torch.from_numpy(a).cuda() for a in (g["p"][None], g["n"][None], g["feat"]))
+    CH = int(g["chunk"])
+    A = snm.construction_affinity_matrix_normal(P, Nn, sigma=0.1, knn=50)
+    # farthest-50 selection: near-ties at the 50th distance resolve differently in torch.topk on the device and on
+    # the CPU the fixture was captured on (the oracle test makes the same allowance) -> entry-wise agreement, mostly
+    Ad = A[0, :40].cpu().numpy()
+    agree = np.isclose(Ad, g["A_rows"], rtol=2e-4, atol=1e-9)
+    assert agree.mean() > 0.9, agree.mean()
+    np.testing.assert_allclose(float(snm.compute_entropy(Ft, CHUNK=CH)), g["ent_feat"], rtol=1e-4)
+    np.testing.assert_allclose(float(snm.compute_entropy(torch.from_numpy(g["v"]).cuda(), CHUNK=CH)), g["ent_v"], rtol=1e-4)
+    torch.manual_seed(7)
+    out = snm.hpnet_process(Ft, P, Nn, normal_smooth_w=0.5, CHUNK=CH).cpu().numpy()
+    assert out.shape == g["out"].shape == (1, 600, 28)
+    # the embedding block is deterministic: feat * (1.7 - entropy)
+    np.testing.assert_allclose(out[..., :16], g["out"][..., :16], rtol=1e-4, atol=1e-6)
+    # the spectral block: unit rows, and the 12-d subspace agrees with the reference's (lobpcg is an
+    # unconverged random-start iteration: compare through principal angles)
+    v, vr = out[0, :, 16:], g["out"][0, :, 16:]
+    qa, _ = np.linalg.qr(v)
+    qb, _ = np.linalg.qr(vr)
+    sv = np.linalg.svd(qa.T @ qb, compute_uv=False)
+    # device RNG stream != the CPU stream the fixture was seeded with, and 10 lobpcg iterations do not converge the
+    # trailing directions: the leading half of the subspace must agree, the rest is only checked for shape / norm
+    assert (sv > 0.75).sum() >= 6, sv
+
+
+
+@pytest.mark.parametrize("N,K,CH", [(1000, 128, 150), (777, 12, 2000), (2500, 8, 400), (130, 140, 64)])
+def test_entropy_kernel_matches_oracle(T, N, K, CH):
+    """Ragged tiles, K not a multiple of the staging chunk, coverage cut at ITER * CHUNK < N."""
+    from oracle import hpnet as ohp
+    from src import smooth_normal_matrix as snm
+    rng = np.random.default_rng(N + K)
+    f = (rng.normal(size=(N, K)) * rng.uniform(0.1, 3.0, size=K)).astype(np.float32)
+    got = float(snm.compute_entropy(T.from_numpy(f[None]).cuda(), CHUNK=CH))
+    np.testing.assert_allclose(got, ohp.compute_entropy(f, CH), rtol=2e-5)
+
+
+def test_entropy_needs_device_tensors(T):
+    from src import smooth_normal_matrix as snm
+    with pytest.raises(RuntimeError):
+        snm.compute_entropy(T.zeros(1, 64, 8))

@@ -69,9 +69,15 @@ int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, 
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                        sed_stream_t stream);
-/* d = 128 has two kernels that differ only in the order tile contributions are summed: batched (one workgroup = 128
- * queries, all keys) and split-key (one workgroup = 32 queries, keys split over 8 waves; for grids that would leave CUs
- * idle, i.e. the reference script's batch of 1). 0 = choose by grid size (default), 1 = batched, 2 = split-key. */
+/* Same, with a caller-owned workspace of sed_ms_iterate_workspace_bytes(B, N, d) bytes (0 = none needed): small
+ * batches at d = 128 (the reference script's one cloud per call) then run the key-chunked variant, which splits the
+ * key sweep of every 128-query block over several workgroups per iteration so that all CUs have work. */
+size_t sed_ms_iterate_workspace_bytes(int B, int N, int d);
+int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                          void* workspace, size_t workspace_bytes, sed_stream_t stream);
+/* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
+ * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
+ * variant above). 0 = choose by grid size (default), 1 = batched, 2 = split-key, 3 = key-chunked (tests, measurements). */
 int sed_ms_set_variant(int variant);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),

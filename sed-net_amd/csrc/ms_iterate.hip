@@ -466,18 +466,217 @@ __global__ __launch_bounds__(512, 2) void ms_iterate_d128_splitk_kernel(const fl
     }
 }
 
-int g_ms_variant = 0;      // 0 = choose by grid size, 1 = batched kernel, 2 = split-key kernel
+// ------------------------------------------------------------------------------------------------------------
+// D = 128, few clouds: key-chunked variant, one launch pair per iteration.
+// The batched kernel's workgroup (128 queries x all keys x all iterations) is the unit of parallelism, and 1..8 clouds
+// give only 79..632 of them for 256 CUs. Here one workgroup = 128 queries x ONE CHUNK of the 64-key stages x ONE
+// iteration (same inner loop as ms_iterate_d128_kernel), writing its un-normalised partial (O, sum) to a workspace;
+// ms_combine_d128_kernel adds the chunks in fixed order, applies the update + row normalisation and writes the new
+// iterate. Stream order is the grid barrier (2 x iters launches, ~5 us each against ~0.4 ms of work per iteration).
+__global__ __launch_bounds__(256, 2) void ms_partial_d128_kernel(const float* __restrict__ X,
+                                                                 const float* __restrict__ Q,
+                                                                 const float* __restrict__ bw, int N, int nchunk,
+                                                                 float* __restrict__ partO,
+                                                                 float* __restrict__ partS) {
+    constexpr int D = 128, LDX = 132, C4 = 32, KT = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // [2][KT * LDX]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int chunk = blockIdx.x, bx = blockIdx.y, cloud = blockIdx.z;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = bx * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const float b = bw[cloud];
+    const float neg_half_inv_b2 = -0.5f / (b * b);
+    const int nst = (N + KT - 1) / KT;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    float q[4][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f32x4 v = *(const f32x4*)(Q + ((size_t)cloud * N + qrow_c) * D + 4 * mfma_row(r, hi));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c][r] = v[c];
+    }
+    f32x4 stage[8];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * KT + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(lds_dyn + buf * KT * LDX + row * LDX + 4 * c4) = stage[u];
+        }
+    };
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    if (s0 < s1) {
+        stage_load(s0);
+        stage_store(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = s0; tile < s1; ++tile) {
+        const bool last = tile == s1 - 1;
+        if (!last) stage_load(tile + 1);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const float* xt = lds_dyn + cur * KT * LDX + sub * 32 * LDX;
+            const int key0 = tile * KT + sub * 32;
+            if (key0 < N) {                                   // block-uniform
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 4 * mfma_row(r, hi));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[c][r], s);
+                }
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dist = 2.0f - 2.0f * s[r];
+                    float a = dist * neg_half_inv_b2;
+                    a = fminf(fmaxf(a, -75.0f), 75.0f);
+                    p[r] = exp_compensated(a);
+                }
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rsum += p[r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 xb = *(const f32x4*)(xt + mfma_row(r, hi) * LDX + 4 * li);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = mfma32(xb[c], p[r], o[c]);
+                }
+            }
+        }
+        if (!last) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float rs = rsum + xor32(rsum);
+    if (qrow < N) {
+        const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+        float* out = partO + slot * D;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 v = {o[0][r], o[1][r], o[2][r], o[3][r]};
+            *(f32x4*)(out + 4 * mfma_row(r, hi)) = v;
+        }
+        if (hi == 0) partS[slot] = rs;
+    }
+}
+
+// new Q = normalize(Q + (sum_chunks O / sum_chunks S - Q)); 32 lanes x float4 per query row, 8 rows per workgroup
+__global__ __launch_bounds__(256) void ms_combine_d128_kernel(const float* __restrict__ partO,
+                                                              const float* __restrict__ partS,
+                                                              const float* __restrict__ Qin, float* __restrict__ Qout,
+                                                              size_t rows, int nchunk) {
+    constexpr int D = 128;
+    const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l = threadIdx.x & 31;
+    if (row >= rows) return;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        const f32x4 v = *(const f32x4*)(partO + (row * nchunk + c) * D + 4 * l);
+        o += v;
+        rs += partS[row * nchunk + c];
+    }
+    const f32x4 q = *(const f32x4*)(Qin + row * D + 4 * l);
+    const float Dinv = 1.0f / rs;
+    f32x4 nq;
+    float n2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float m = o[e] * Dinv - q[e];
+        nq[e] = q[e] + m;
+        n2 += nq[e] * nq[e];
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+    const float nrm = sqrtf(n2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nq[e] = nq[e] / nrm;
+    *(f32x4*)(Qout + row * D + 4 * l) = nq;
+}
+
+// Schedules for d = 128 and their cost model (units: one batched workgroup alone on a CU = 1; 256 CUs; measured):
+//   batched      ceil(W / 256),                W = B * ceil(N / 128)
+//   split-key    0.36 * ceil(W4 / 256),        W4 = B * ceil(N / 32)
+//   key-chunked  1.10 * ceil(W * S / 256) / S + 0.02   (partial traffic ~10 %, launch pairs)
+// The chunk count S depends on N only (about 10 stages of 64 keys per chunk), so the summation order -- hence the
+// result bits -- of a cloud does not depend on how many clouds share the launch.
+int ms_chunks(int N) {
+    const int nst = (N + 63) / 64;
+    if (nst < 40) return 0;                       // short sweeps: one launch for all iterations is cheaper
+    int S = (nst + 5) / 10;
+    return S < 2 ? 2 : (S > 32 ? 32 : S);
+}
+
+enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3 };
+
+int ms_plan(int B, int N, bool have_ws, int forced) {
+    const long W = (long)B * ((N + 127) / 128), W4 = (long)B * ((N + 31) / 32);
+    const int S = ms_chunks(N);
+    if (forced == MS_CHUNKED) return (S && have_ws) ? MS_CHUNKED : MS_BATCHED;
+    if (forced) return forced;
+    const double cb = (double)((W + 255) / 256);
+    const double ck = 0.36 * (double)((W4 + 255) / 256);
+    const double cc = (S && have_ws) ? 1.10 * (double)((W * S + 255) / 256) / S + 0.02 : 1e30;
+    if (cc < cb && cc < ck) return MS_CHUNKED;
+    return ck < cb ? MS_SPLITK : MS_BATCHED;
+}
+
+int g_ms_variant = 0;      // 0 = choose by grid size, 1 = batched kernel, 2 = split-key kernel, 3 = key-chunked launches
 
 }  // namespace
 
 extern "C" int sed_ms_set_variant(int variant) {
-    if (variant < 0 || variant > 2) return SED_EINVAL;
+    if (variant < 0 || variant > 3) return SED_EINVAL;
     g_ms_variant = variant;
     return SED_OK;
 }
 
+extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
+    if (d != 128 || B <= 0 || N <= 0) return 0;
+    if (ms_plan(B, N, true, g_ms_variant) != MS_CHUNKED) return 0;
+    return (size_t)B * N * ms_chunks(N) * (128 + 1) * sizeof(float);
+}
+
+// Same contract as sed_ms_iterate_f32 plus a caller-owned workspace (sed_ms_iterate_workspace_bytes): with it, small
+// batches at d = 128 run the key-chunked variant (one launch pair per iteration) that keeps all CUs busy.
+extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                                     void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   hipStream_t stream) {
+    return sed_ms_iterate_ws_f32(B, N, d, iters, bw, X, newX, nullptr, 0, stream);
+}
+
+extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     dim3 grid((N + 127) / 128, B), block(256);
@@ -486,13 +685,31 @@ extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* b
         case 2: ms_iterate_kernel<2><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 3: ms_iterate_kernel<3><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 4: {
-            // few workgroups (single clouds): split the key sweep over 8 waves so that more CUs have work. Cost model
-            // (measured, 256 CUs, one resident workgroup of either kernel per CU at full speed): a split-key workgroup
-            // takes ~0.36 of a batched workgroup's time; each grid needs ceil(workgroups / 256) rounds.
-            const long rounds_b = ((long)B * ((N + 127) / 128) + 255) / 256;
-            const long rounds_k = ((long)B * ((N + 31) / 32) + 255) / 256;
-            const bool splitk = g_ms_variant == 2 || (g_ms_variant == 0 && 36 * rounds_k < 100 * rounds_b);
-            if (splitk) {
+            const int S = ms_chunks(N);
+            const size_t need = (size_t)B * N * S * (128 + 1) * sizeof(float);
+            const int plan = ms_plan(B, N, iters > 0 && workspace && workspace_bytes >= need, g_ms_variant);
+            const bool chunked = plan == MS_CHUNKED;
+            if (chunked) {
+                constexpr int smc = 2 * 64 * 132 * (int)sizeof(float);
+                static bool attr_c = false;
+                if (!attr_c) {
+                    hipError_t e = hipFuncSetAttribute((const void*)ms_partial_d128_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, smc);
+                    if (e != hipSuccess) return (int)e;
+                    attr_c = true;
+                }
+                float* partO = (float*)workspace;
+                float* partS = partO + (size_t)B * N * S * 128;
+                const size_t rows = (size_t)B * N;
+                for (int it = 0; it < iters; ++it) {
+                    ms_partial_d128_kernel<<<dim3(S, (N + 127) / 128, B), 256, smc, stream>>>(
+                        X, it == 0 ? X : newX, bw, N, S, partO, partS);
+                    ms_combine_d128_kernel<<<(unsigned)((rows + 7) / 8), 256, 0, stream>>>(
+                        partO, partS, it == 0 ? X : newX, newX, rows, S);
+                }
+                break;
+            }
+            if (plan == MS_SPLITK) {
                 constexpr int smk = 8 * 32 * 132 * (int)sizeof(float);     // 132 KiB
                 static bool attr_k = false;
                 if (!attr_k) {

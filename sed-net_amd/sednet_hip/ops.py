@@ -135,7 +135,10 @@ def ms_iterate(X, bw, iters):
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.sed_ms_iterate_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), stream()), "ms_iterate")
+    nws = lib.sed_ms_iterate_workspace_bytes(B, N, D)      # > 0: few clouds, the key-chunked schedule fills the CUs
+    ws = torch.empty((nws,), dtype=torch.uint8, device=X.device) if nws else None
+    check(lib.sed_ms_iterate_ws_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), ptr(ws) if nws else None, nws,
+                                    stream()), "ms_iterate")
     if TIMERS is not None:
         ev1.record()
         TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
@@ -143,8 +146,9 @@ def ms_iterate(X, bw, iters):
 
 
 def ms_set_variant(variant):
-    """Force the d = 128 mean-shift kernel: "auto" (by grid size), "batched" or "splitk" (tests / measurements)."""
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2}[variant]), "ms_set_variant")
+    """Force the d = 128 mean-shift schedule: "auto" (by grid size), "batched", "splitk" or "chunked"
+    (tests / measurements)."""
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3}[variant]), "ms_set_variant")
 
 
 def ms_nms(centres, X, bw):

@@ -44,7 +44,7 @@ def variant(request):
     ops.ms_set_variant("auto")
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk"], indirect=True)
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked"], indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
@@ -96,7 +96,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk"):
+        for v in ("batched", "splitk", "chunked"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -105,10 +105,11 @@ def test_iteration_variants_agree_at_full_size(T):
         ops.ms_set_variant("auto")
     # 50 iterations amplify the rounding differences of points still moving (the golden test allows 1e-5 too)
     np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
-    assert np.isfinite(res["splitk"]).all()
+    np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
+    assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all()
     one = {}
     try:
-        for v in ("batched", "splitk"):
+        for v in ("batched", "splitk", "chunked"):
             ops.ms_set_variant(v)
             one[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()
     finally:
@@ -122,6 +123,7 @@ def test_iteration_variants_agree_at_full_size(T):
     ref = p @ x64 / p.sum(1, keepdims=True)
     ref /= np.linalg.norm(ref, axis=1, keepdims=True)
     np.testing.assert_allclose(one["splitk"][0][rows], ref, atol=3e-6)
+    np.testing.assert_allclose(one["chunked"][0][rows], ref, atol=5e-6)
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
 

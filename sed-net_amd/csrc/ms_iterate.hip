@@ -467,6 +467,127 @@ __global__ __launch_bounds__(512, 2) void ms_iterate_d128_splitk_kernel(const fl
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Key-chunked schedule for the generic widths (d = 140 -> 160 with the HPNet columns is the reference script's default
+// flow, one cloud per call): one workgroup = 128 queries x one chunk of the 32-key tiles x ONE iteration of
+// ms_iterate_kernel's inner loop; un-normalised partial (O, sum) to the workspace, ms_combine_kernel finishes the
+// iteration. See the D = 128 twin below for the rationale.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void ms_partial_kernel(const float* __restrict__ X, const float* __restrict__ Q,
+                                                            const float* __restrict__ bw, int N, int nchunk,
+                                                            float* __restrict__ partO, float* __restrict__ partS) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int chunk = blockIdx.x, bx = blockIdx.y, cloud = blockIdx.z;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = bx * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const float b = bw[cloud];
+    const float neg_half_inv_b2 = -0.5f / (b * b);
+    const int ntiles = (N + 31) >> 5;
+    const int t0 = (int)((long)chunk * ntiles / nchunk), t1 = (int)((long)(chunk + 1) * ntiles / nchunk);
+
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Q + ((size_t)cloud * N + qrow_c) * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    f32x4 stage[NT];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+    };
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float rsum = 0.f;
+    if (t0 < t1) {
+        stage_load(t0);
+        stage_store(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const bool last = tile == t1 - 1;
+        if (!last) stage_load(tile + 1);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);
+            }
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dist = 2.0f - 2.0f * s[r];
+            float a = dist * neg_half_inv_b2;
+            a = fminf(fmaxf(a, -75.0f), 75.0f);
+            p[r] = exp_compensated(a);
+        }
+        if (tile == ntiles - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tile * 32 + mfma_row(r, hi) >= N) p[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rsum += p[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* xr = xt + mfma_row(r, hi) * LDX + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = mfma32(xr[32 * t], p[r], o[t]);
+        }
+        if (!last) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float rs = rsum + xor32(rsum);
+    if (qrow < N) {
+        const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+        float* out = partO + slot * D;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[t][4 * g], o[t][4 * g + 1], o[t][4 * g + 2], o[t][4 * g + 3]};
+                *(f32x4*)(out + 32 * t + 8 * g + 4 * hi) = v;
+            }
+        if (hi == 0) partS[slot] = rs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // D = 128, few clouds: key-chunked variant, one launch pair per iteration.
 // The batched kernel's workgroup (128 queries x all keys x all iterations) is the unit of parallelism, and 1..8 clouds
 // give only 79..632 of them for 256 CUs. Here one workgroup = 128 queries x ONE CHUNK of the 64-key stages x ONE
@@ -588,23 +709,24 @@ __global__ __launch_bounds__(256, 2) void ms_partial_d128_kernel(const float* __
     }
 }
 
-// new Q = normalize(Q + (sum_chunks O / sum_chunks S - Q)); 32 lanes x float4 per query row, 8 rows per workgroup
-__global__ __launch_bounds__(256) void ms_combine_d128_kernel(const float* __restrict__ partO,
-                                                              const float* __restrict__ partS,
-                                                              const float* __restrict__ Qin, float* __restrict__ Qout,
-                                                              size_t rows, int nchunk) {
-    constexpr int D = 128;
-    const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int l = threadIdx.x & 31;
+// new Q = normalize(Q + (sum_chunks O / sum_chunks S - Q)); one wave per query row (D / 4 <= 64 lanes x float4),
+// 4 rows per workgroup
+__global__ __launch_bounds__(256) void ms_combine_kernel(const float* __restrict__ partO,
+                                                         const float* __restrict__ partS,
+                                                         const float* __restrict__ Qin, float* __restrict__ Qout,
+                                                         size_t rows, int nchunk, int D) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
     if (row >= rows) return;
+    const bool act = 4 * l < D;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     float rs = 0.f;
     for (int c = 0; c < nchunk; ++c) {
-        const f32x4 v = *(const f32x4*)(partO + (row * nchunk + c) * D + 4 * l);
-        o += v;
+        if (act) o += *(const f32x4*)(partO + (row * nchunk + c) * D + 4 * l);
         rs += partS[row * nchunk + c];
     }
-    const f32x4 q = *(const f32x4*)(Qin + row * D + 4 * l);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (act) q = *(const f32x4*)(Qin + row * D + 4 * l);
     const float Dinv = 1.0f / rs;
     f32x4 nq;
     float n2 = 0.f;
@@ -615,16 +737,18 @@ __global__ __launch_bounds__(256) void ms_combine_d128_kernel(const float* __res
         n2 += nq[e] * nq[e];
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+    for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
     const float nrm = sqrtf(n2);
+    if (act) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) nq[e] = nq[e] / nrm;
-    *(f32x4*)(Qout + row * D + 4 * l) = nq;
+        for (int e = 0; e < 4; ++e) nq[e] = nq[e] / nrm;
+        *(f32x4*)(Qout + row * D + 4 * l) = nq;
+    }
 }
 
-// Schedules for d = 128 and their cost model (units: one batched workgroup alone on a CU = 1; 256 CUs; measured):
+// Schedules and their cost model (units: one batched workgroup alone on a CU = 1; 256 CUs; measured at d = 128):
 //   batched      ceil(W / 256),                W = B * ceil(N / 128)
-//   split-key    0.36 * ceil(W4 / 256),        W4 = B * ceil(N / 32)
+//   split-key    0.36 * ceil(W4 / 256),        W4 = B * ceil(N / 32)          (d = 128 only)
 //   key-chunked  1.10 * ceil(W * S / 256) / S + 0.02   (partial traffic ~10 %, launch pairs)
 // The chunk count S depends on N only (about 10 stages of 64 keys per chunk), so the summation order -- hence the
 // result bits -- of a cloud does not depend on how many clouds share the launch.
@@ -637,13 +761,14 @@ int ms_chunks(int N) {
 
 enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3 };
 
-int ms_plan(int B, int N, bool have_ws, int forced) {
+int ms_plan(int B, int N, int d, bool have_ws, int forced) {
     const long W = (long)B * ((N + 127) / 128), W4 = (long)B * ((N + 31) / 32);
     const int S = ms_chunks(N);
     if (forced == MS_CHUNKED) return (S && have_ws) ? MS_CHUNKED : MS_BATCHED;
+    if (forced == MS_SPLITK && d != 128) return MS_BATCHED;
     if (forced) return forced;
     const double cb = (double)((W + 255) / 256);
-    const double ck = 0.36 * (double)((W4 + 255) / 256);
+    const double ck = d == 128 ? 0.36 * (double)((W4 + 255) / 256) : 1e30;
     const double cc = (S && have_ws) ? 1.10 * (double)((W * S + 255) / 256) / S + 0.02 : 1e30;
     if (cc < cb && cc < ck) return MS_CHUNKED;
     return ck < cb ? MS_SPLITK : MS_BATCHED;
@@ -660,9 +785,9 @@ extern "C" int sed_ms_set_variant(int variant) {
 }
 
 extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
-    if (d != 128 || B <= 0 || N <= 0) return 0;
-    if (ms_plan(B, N, true, g_ms_variant) != MS_CHUNKED) return 0;
-    return (size_t)B * N * ms_chunks(N) * (128 + 1) * sizeof(float);
+    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
+    if (ms_plan(B, N, d, true, g_ms_variant) != MS_CHUNKED) return 0;
+    return (size_t)B * N * ms_chunks(N) * (d + 1) * sizeof(float);
 }
 
 // Same contract as sed_ms_iterate_f32 plus a caller-owned workspace (sed_ms_iterate_workspace_bytes): with it, small
@@ -680,35 +805,43 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     dim3 grid((N + 127) / 128, B), block(256);
+    const int S = ms_chunks(N);
+    const size_t need = (size_t)B * N * S * (d + 1) * sizeof(float);
+    const int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, g_ms_variant);
+    if (plan == MS_CHUNKED) {
+        float* partO = (float*)workspace;
+        float* partS = partO + (size_t)B * N * S * d;
+        const size_t rows = (size_t)B * N;
+        const dim3 pgrid(S, (N + 127) / 128, B);
+        constexpr int smc = 2 * 64 * 132 * (int)sizeof(float);
+        if (d == 128) {
+            static bool attr_c = false;
+            if (!attr_c) {
+                hipError_t e = hipFuncSetAttribute((const void*)ms_partial_d128_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, smc);
+                if (e != hipSuccess) return (int)e;
+                attr_c = true;
+            }
+        }
+        for (int it = 0; it < iters; ++it) {
+            const float* Q = it == 0 ? X : newX;
+            switch (d / 32) {
+                case 1: ms_partial_kernel<1><<<pgrid, 256, 0, stream>>>(X, Q, bw, N, S, partO, partS); break;
+                case 2: ms_partial_kernel<2><<<pgrid, 256, 0, stream>>>(X, Q, bw, N, S, partO, partS); break;
+                case 3: ms_partial_kernel<3><<<pgrid, 256, 0, stream>>>(X, Q, bw, N, S, partO, partS); break;
+                case 4: ms_partial_d128_kernel<<<pgrid, 256, smc, stream>>>(X, Q, bw, N, S, partO, partS); break;
+                case 5: ms_partial_kernel<5><<<pgrid, 256, 0, stream>>>(X, Q, bw, N, S, partO, partS); break;
+            }
+            ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Q, newX, rows, S, d);
+        }
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
     switch (d / 32) {
         case 1: ms_iterate_kernel<1><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 2: ms_iterate_kernel<2><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 3: ms_iterate_kernel<3><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
         case 4: {
-            const int S = ms_chunks(N);
-            const size_t need = (size_t)B * N * S * (128 + 1) * sizeof(float);
-            const int plan = ms_plan(B, N, iters > 0 && workspace && workspace_bytes >= need, g_ms_variant);
-            const bool chunked = plan == MS_CHUNKED;
-            if (chunked) {
-                constexpr int smc = 2 * 64 * 132 * (int)sizeof(float);
-                static bool attr_c = false;
-                if (!attr_c) {
-                    hipError_t e = hipFuncSetAttribute((const void*)ms_partial_d128_kernel,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, smc);
-                    if (e != hipSuccess) return (int)e;
-                    attr_c = true;
-                }
-                float* partO = (float*)workspace;
-                float* partS = partO + (size_t)B * N * S * 128;
-                const size_t rows = (size_t)B * N;
-                for (int it = 0; it < iters; ++it) {
-                    ms_partial_d128_kernel<<<dim3(S, (N + 127) / 128, B), 256, smc, stream>>>(
-                        X, it == 0 ? X : newX, bw, N, S, partO, partS);
-                    ms_combine_d128_kernel<<<(unsigned)((rows + 7) / 8), 256, 0, stream>>>(
-                        partO, partS, it == 0 ? X : newX, newX, rows, S);
-                }
-                break;
-            }
             if (plan == MS_SPLITK) {
                 constexpr int smk = 8 * 32 * 132 * (int)sizeof(float);     // 132 KiB
                 static bool attr_k = false;

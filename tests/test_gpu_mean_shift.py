@@ -127,6 +127,34 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
 
+def test_chunked_schedule_other_widths(T):
+    """d = 140 (HPNet columns) -> padded 160, and d = 64: the key-chunked schedule against the batched kernel and fp64."""
+    from sednet_hip import ops, synth
+    for d, N in ((140, 6000), (64, 4100)):
+        Xs, _ = synth.clustered_embedding(N=N, d=d, n_clusters=8, sigma=0.02, seed=d)
+        X = ops.pad_features(dev(T, Xs[None]))
+        bw = ops.ms_bandwidth(X, 90, 0.003)
+        res = {}
+        try:
+            for v in ("batched", "chunked"):
+                ops.ms_set_variant(v)
+                res[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()[0]
+                res[v + "50"] = ops.ms_iterate(X, bw, 50).cpu().numpy()[0]
+        finally:
+            ops.ms_set_variant("auto")
+        auto = ops.ms_iterate(X, bw, 50).cpu().numpy()[0]
+        np.testing.assert_array_equal(auto, res["chunked50"])               # one cloud of this size: auto = chunked
+        np.testing.assert_allclose(res["batched50"], res["chunked50"], atol=2e-5)
+        x64 = X[0].cpu().numpy().astype(np.float64)
+        rows = np.arange(0, N, 61)
+        b = float(bw[0])
+        p = np.exp(-0.5 * (2.0 - 2.0 * x64[rows] @ x64.T) / (b * b))
+        ref = p @ x64 / p.sum(1, keepdims=True)
+        ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+        np.testing.assert_allclose(res["chunked"][rows], ref, atol=5e-6)
+        np.testing.assert_allclose(res["batched"][rows], ref, atol=3e-5)
+
+
 def test_guard_loop_matches_golden(T, golden):
     """> 49 clusters on the first passes -> quantile *= 1.2 until the twin clusters merge
     (generate_predictions_aug.py:25-35)."""

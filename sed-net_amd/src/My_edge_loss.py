@@ -19,17 +19,19 @@ def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
     pull = torch.zeros(1, device=dev)
     push = torch.zeros(1, device=dev)
     for i in range(B):
-        segs = [pred_feat[i][gt_label[i] == v] for v in torch.unique(gt_label[i]).tolist()]
-        cents = [s.mean(0, keepdim=True) for s in segs]
-        intra = torch.zeros(1, device=dev)
-        for s, c in zip(segs, cents):
-            intra = intra + F.relu(torch.norm(s - c, 2, dim=1) - t_pull).mean()
-        pull = pull + intra / len(segs)
-        C = torch.cat(cents, 0)
-        if C.shape[0] == 1:
+        # segment statistics by scatter-add instead of the reference's per-segment Python loop (same terms)
+        _, inv, cnt = torch.unique(gt_label[i], return_inverse=True, return_counts=True)
+        S = cnt.shape[0]
+        cntf = cnt.to(pred_feat.dtype)
+        C = torch.zeros((S, pred_feat.shape[2]), dtype=pred_feat.dtype, device=dev).index_add_(0, inv, pred_feat[i])
+        C = C / cntf[:, None]
+        excess = F.relu(torch.norm(pred_feat[i] - C[inv], 2, dim=1) - t_pull)
+        per_seg = torch.zeros(S, dtype=pred_feat.dtype, device=dev).index_add_(0, inv, excess) / cntf
+        pull = pull + per_seg.sum() / S
+        if S == 1:
             continue
         dist = torch.norm(C[:, None, :] - C[None, :, :], 2, dim=2)
-        off = dist[~torch.eye(C.shape[0], dtype=torch.bool, device=dev)]
+        off = dist[~torch.eye(S, dtype=torch.bool, device=dev)]
         push = push + F.relu(t_push - off).mean()
     pull, push = pull / B, push / B
     return pull + push, pull, push

@@ -29,8 +29,10 @@ class EmbeddingLoss:
         for i in range(B):
             uniq = np.unique(labels[i])
             n_s = min(N // uniq.shape[0] + 1, 30)
-            picks.append({l: np.random.choice(list(np.where(np.isin(labels[i], l))[0]), n_s, replace=True)
+            picks.append({l: np.random.choice(np.where(labels[i] == l)[0], n_s, replace=True)
                           for l in uniq})
+        # all np.random draws happen on the host in the reference's order; the tensor work of one cloud is then batched
+        # over its sampled segment pairs instead of the reference's per-pair Python loop (same terms, one launch set)
         total = torch.zeros(1, device=dev)
         single = 0
         for i in range(B):
@@ -39,23 +41,23 @@ class EmbeddingLoss:
             if nk == 1:
                 single += 1
                 continue
-            acc = torch.zeros(1, device=dev)
-            used = 0
+            pairs = []
             for _ in range(min(max_segments * max_segments, nk * nk)):
                 k1 = np.random.choice(nk, 1)[0]
                 k2 = np.random.choice(nk, 1)[0]
-                if k1 == k2:
-                    continue
-                used += 1
-                a = out[i, torch.as_tensor(picks[i][keys[k1]], device=dev)]
-                b = out[i, torch.as_tensor(picks[i][keys[k2]], device=dev)]
-                d_pos = ((a[:, None] - a[None]) ** 2).sum(2)
-                d_neg = ((a[:, None] - b[None]) ** 2).sum(2)
-                viol = F.relu(d_pos - d_neg + self.margin)
-                hinge = viol.sum() - viol.trace()                    # anchor == positive on the diagonal
-                active = ((viol > 0).sum() + 1.0).float().detach()
-                acc = acc + hinge / active
-            total = total + acc / (used + 1e-8)
+                if k1 != k2:
+                    pairs.append((k1, k2))
+            if not pairs:
+                continue                                             # acc = 0 / (0 + 1e-8)
+            seg = out[i, torch.as_tensor(np.stack([picks[i][k] for k in keys]), device=dev)]     # [nk, ns, D]
+            pr = torch.as_tensor(np.asarray(pairs), device=dev)
+            a, b = seg[pr[:, 0]], seg[pr[:, 1]]                                                   # [P, ns, D]
+            d_pos = ((a[:, :, None] - a[:, None]) ** 2).sum(3)
+            d_neg = ((a[:, :, None] - b[:, None]) ** 2).sum(3)
+            viol = F.relu(d_pos - d_neg + self.margin)                                            # [P, ns, ns]
+            hinge = viol.sum((1, 2)) - torch.diagonal(viol, dim1=1, dim2=2).sum(1)                # anchor == positive
+            active = ((viol > 0).sum((1, 2)) + 1.0).float().detach()
+            total = total + (hinge / active).sum() / (len(pairs) + 1e-8)
         return total / (B - single + 1e-8)
 
 

@@ -4,10 +4,11 @@ Test infrastructure only -- see oracle/__init__.py.
 Follows /root/reference/src/chamfer_distance/chamfer_distance.cu:6-205 (and its CPU twin chamfer_distance.cpp:59-177,
 which accumulates the distance in double) and
 /root/reference/Fitting_patches_and_edges/pointnet2/_ext_src/src/{sampling,ball_query,group_points,interpolate}_gpu.cu.
-PARITY UNPINNED: the reference holds no golden vectors or asserting tests for these ops, its CUDA kernels cannot run
-here, and its chamfer C++ twin is a torch extension whose build also needs the CUDA launchers (unbuildable without
-stand-ins, which are not allowed). This restatement is therefore checked only by analytic properties and by an
-independent torch-autograd chamfer (the pure-torch twin src/utils.py:273-296), tests/test_oracle_pointops.py.
+Chamfer: pinned by tests/golden/f_chamfer.npz -- values, one-sided values, guarded-sqrt value and autograd gradients of
+the reference's own pure-torch twin (src/utils.py:273-322), captured by make_golden.py gen_chamfer.
+PointNet++ operator set: PARITY UNPINNED -- the reference holds no golden vectors or asserting tests for these ops, its
+CUDA kernels cannot run here (the chamfer C++ twin is a torch extension whose build also needs the CUDA launchers,
+unbuildable without stand-ins, which are not allowed); checked only by analytic properties (tests/test_oracle_pointops.py).
 """
 import numpy as np
 

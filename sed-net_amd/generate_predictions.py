@@ -30,7 +30,7 @@ from read_config import Config                      # noqa: E402
 from sednet_hip import ops, synth                    # noqa: E402
 from src.mean_shift import MeanShift                 # noqa: E402
 from src.SEDNet import SEDNet                        # noqa: E402
-from src.segment_utils import seg_iou                # noqa: E402
+from src.segment_utils import SIOU_matched_segments_usecd, seg_iou                # noqa: E402
 
 DROP_OUT_NUM = 2000                                  # generate_predictions_aug.py:65
 ITERATIONS, QUANTILE = 50, 0.015                     # :188-189
@@ -128,7 +128,7 @@ def main(argv=None):
     if args.save == "Save":
         os.makedirs(args.out, exist_ok=True)
 
-    s_ious = []
+    s_ious, p_ious, recalls = [], [], []
     for b0 in range(0, len(ids), args.batch):
         x = torch.from_numpy(x_all[b0:b0 + args.batch]).to(device)
         with torch.no_grad():
@@ -147,7 +147,15 @@ def main(argv=None):
             cid = ids[b0 + i]
             msg = f"ID:{cid} | clusters {n_labels[i]} (passes {passes[i]})"
             gt = labels_all[b0 + i] if labels_all is not None else None
-            if gt is not None:
+            if gt is not None and types_all is not None:                                                 # :389-410
+                w = torch.nn.functional.one_hot(labels[i].long(), 50).float()
+                s, p, _, _, rec = SIOU_matched_segments_usecd(np.asarray(gt).astype(np.int64), labels_h[i].astype(np.int64),
+                                                              types_h[i].astype(np.int64).copy(),
+                                                              np.asarray(types_all[b0 + i]).astype(np.int64).copy(), w,
+                                                              x[i, 0:3].t().contiguous())
+                s_ious.append(s); p_ious.append(p); recalls.append(rec)
+                msg += f" inst_iou: {s:.4f} type_iou: {p:.4f} inst_recall: {rec:.4f}"
+            elif gt is not None:
                 s = seg_iou(labels_h[i], gt)
                 s_ious.append(s)
                 msg += f" inst_iou: {s:.4f}"
@@ -156,8 +164,11 @@ def main(argv=None):
                 np.savetxt(os.path.join(args.out, f"{cid}_inst.txt"), labels_h[i], fmt="%d")            # :427
                 np.savetxt(os.path.join(args.out, f"{cid}_type.txt"), types_h[i], fmt="%d")             # :428
                 np.savetxt(os.path.join(args.out, f"{cid}_edge.txt"), edge_h[i], fmt="%0.4f", delimiter=";")   # :437
-    if s_ious:
-        log.info("===========> inst_iou: %s", np.mean(s_ious))                      # :441
+    if p_ious:
+        log.info("===========> inst_iou: %s  type_iou: %s  inst_recall: %s", np.mean(s_ious), np.mean(p_ious),
+                 np.mean(recalls))                                                    # :441
+    elif s_ious:
+        log.info("===========> inst_iou: %s", np.mean(s_ious))
     return 0
 
 

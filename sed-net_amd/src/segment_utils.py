@@ -80,3 +80,59 @@ def SIOU_matched_segments(target, pred_labels, primitives_pred, primitives, weig
         total += 1
         hits += int(np.bincount(primitives_pred[pi]).argmax() == np.bincount(primitives[gi]).argmax())
     return s_iou, hits / max(total, 1), [[rids, cids]]
+
+
+def primitive_type_segment_torch(pred, weights):
+    """Type of every predicted segment = argmax_L sum_n pred[n,L] weights[n,k] (segment_utils.py:509-517)."""
+    return torch.max(pred.t().float() @ weights.float(), 0)[1]
+
+
+def mean_IOU_primitive_segment_usecd(matching, predicted_labels, labels, pred_prim, gt_prim, points):
+    """segment_utils.py:424-494: IoU and type agreement over matched segments, plus the chamfer recall -- a matched pair
+    counts as recalled when the chamfer distance between its two point sets is below 0.2 (cd / 2 < 0.1). The per-pair
+    chamfer runs on the HIP kernels (src/utils.py)."""
+    from src.utils import chamfer_distance
+    IOU, RECALL, IOU_prim = [], [], []
+    pairs = []
+    for b in range(labels.shape[0]):
+        iou_b, prim_b, pairs = [], [], []
+        n_gt = np.unique(labels[b]).shape[0]
+        rows, cols = matching[b]
+        recalled = 0
+        for r, c in zip(rows, cols):
+            pi, gi = predicted_labels[b] == r, labels[b] == c
+            if gi.sum() == 0 or pi.sum() == 0:
+                continue
+            iou_b.append(np.sum(pi & gi) / (np.sum(pi | gi) + 1e-8))
+            sel_p = torch.as_tensor(np.where(pi)[0], device=points.device)
+            sel_g = torch.as_tensor(np.where(gi)[0], device=points.device)
+            if float(chamfer_distance(points[sel_p][None], points[sel_g][None])) / 2 < 0.1:
+                recalled += 1
+            gt_type, pred_type = gt_prim[b][gi][0], pred_prim[b][r]
+            prim_b.append(gt_type == pred_type)
+            pairs.append([gt_type, pred_type])
+        IOU.append(np.mean(iou_b))
+        RECALL.append(float(recalled) / n_gt)
+        IOU_prim.append(np.mean(prim_b))
+    return np.mean(IOU), np.mean(IOU_prim), pairs, np.mean(RECALL)
+
+
+def SIOU_matched_segments_usecd(target, pred_labels, primitives_pred, primitives, weights, points):
+    """segment_utils.py:194-242 (what generate_predictions_aug.py:389 logs): Hungarian matching of predicted and true
+    segments on the relaxed IoU, then (segment IoU, type IoU, matching, [gt, pred] type pairs, chamfer recall).
+    target / pred_labels / primitives* are numpy [N] (type ids folded in place like the reference: {0,6,7} -> 9,
+    8 -> 2), weights [N,K] one-hot / soft membership, points [N,3] on the device."""
+    for a in (primitives, primitives_pred):
+        a[(a == 0) | (a == 6) | (a == 7)] = 9
+        a[a == 8] = 2
+    dev = points.device
+    cost = relaxed_iou_fast(to_one_hot(pred_labels).to(dev).unsqueeze(0).float(),
+                            to_one_hot(target).to(dev).unsqueeze(0).float())
+    rids, cids = linear_sum_assignment(1.0 - cost[0].cpu().numpy())
+    matching = [[rids, cids]]
+    prim_hot = to_one_hot(primitives_pred, 10).to(dev).float()
+    prim_pred = primitive_type_segment_torch(prim_hot, weights.to(dev)).cpu().numpy()
+    s_iou, p_iou, pairs, recall = mean_IOU_primitive_segment_usecd(
+        matching, np.expand_dims(pred_labels, 0), np.expand_dims(target, 0), np.expand_dims(prim_pred, 0),
+        np.expand_dims(primitives, 0), points)
+    return s_iou, p_iou, matching, pairs, recall

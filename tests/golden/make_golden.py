@@ -322,7 +322,44 @@ def gen_train():
     save("f_train", **out)
 
 
+# ----------------------------------------------------------------------------------------
+def gen_chamfer():
+    """F-CD: the reference's pure-torch chamfer twin (src/utils.py:273-322) -- values, one-sided values and autograd
+    gradients -- and its consumer, the seg-IoU metric with the chamfer recall (src/segment_utils.py:194-242, 424-494)."""
+    from src.utils import chamfer_distance, chamfer_distance_one_side
+    from src.segment_utils import SIOU_matched_segments_usecd
+    rng = np.random.default_rng(77)
+    a = rng.normal(size=(2, 600, 3)).astype(F32)
+    b = (rng.normal(size=(2, 300, 3)) * 1.2 + 0.1).astype(F32)
+    ta, tb = t(a).requires_grad_(True), t(b).requires_grad_(True)
+    cd = chamfer_distance(ta, tb)
+    cd.backward()
+    out = {"a": a, "b": b, "cd": cd.detach().numpy(), "cd_sqrt": chamfer_distance(t(a), t(b), sqrt=True).numpy(),
+           "side0": chamfer_distance_one_side(t(a), t(b), side=0).numpy(),
+           "side1": chamfer_distance_one_side(t(a), t(b), side=1).numpy(),
+           "grad_a": ta.grad.numpy(), "grad_b": tb.grad.numpy()}
+    # metric: ground truth = a synthetic cloud's segments, prediction = the same with two segments merged, one split
+    # and 3 % of the points relabelled at random
+    N = 3000
+    p, _, labels, types = synth.synthetic_cloud(123, N, n_prims=7)
+    pred = labels.copy()
+    pred[pred == 6] = 5
+    half = np.where(pred == 0)[0]
+    pred[half[: len(half) // 2]] = 6
+    flip = rng.choice(N, N * 3 // 100, replace=False)
+    pred[flip] = rng.integers(0, 7, size=flip.shape[0])
+    ptype = types.copy()
+    ptype[rng.choice(N, N // 10, replace=False)] = 1
+    w = torch.nn.functional.one_hot(t(pred), 50).float()
+    s_iou, p_iou, matching, _, recall = SIOU_matched_segments_usecd(labels.copy(), pred.copy(), ptype.copy(), types.copy(),
+                                                                    w, t(p))
+    out.update(m_points=p, m_labels=labels.astype(np.int32), m_pred=pred.astype(np.int32), m_types=types.astype(np.int32),
+               m_ptype=ptype.astype(np.int32), m_result=np.array([s_iou, p_iou, recall], np.float64),
+               m_rows=np.asarray(matching[0][0], np.int32), m_cols=np.asarray(matching[0][1], np.int32))
+    save("f_chamfer", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet", "train"]
+    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet", "train", "chamfer"]
     for w in which:
         globals()["gen_" + w]()

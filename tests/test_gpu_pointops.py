@@ -69,3 +69,37 @@ def test_pointnet2_ops(T):
     np.testing.assert_allclose(out.cpu().numpy(), po.three_interpolate(sub, oi3, w), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         pu.furthest_point_sample(T.tensor(xyz), 8)                 # CPU tensors are refused, like the reference
+
+
+def test_chamfer_metric_surface_matches_reference(T, golden):
+    """src/utils.py surface (values, one-sided values, guarded sqrt, gradients through the HIP backward) against the
+    reference's own pure-torch twin (F-CD)."""
+    from src.utils import chamfer_distance, chamfer_distance_one_side
+    g = golden("f_chamfer")
+    a = T.from_numpy(g["a"]).cuda().requires_grad_(True)
+    b = T.from_numpy(g["b"]).cuda().requires_grad_(True)
+    cd = chamfer_distance(a, b)
+    cd.backward()
+    np.testing.assert_allclose(cd.item(), g["cd"], rtol=1e-5)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g["grad_a"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g["grad_b"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(chamfer_distance(g["a"], g["b"], sqrt=True).item(), g["cd_sqrt"], rtol=1e-5)
+    np.testing.assert_allclose(chamfer_distance_one_side(a, b, side=0).item(), g["side0"], rtol=1e-5)
+    np.testing.assert_allclose(chamfer_distance_one_side(a, b, side=1).item(), g["side1"], rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        chamfer_distance(T.zeros(1, 4, 3), T.zeros(1, 4, 3))
+
+
+def test_seg_iou_metric_with_chamfer_recall_matches_reference(T, golden):
+    """SIOU_matched_segments_usecd (what the reference script logs per cloud, generate_predictions_aug.py:389)."""
+    from src.segment_utils import SIOU_matched_segments_usecd
+    g = golden("f_chamfer")
+    pred = g["m_pred"].astype(np.int64)
+    w = T.nn.functional.one_hot(T.from_numpy(pred), 50).float().cuda()
+    s_iou, p_iou, matching, pairs, recall = SIOU_matched_segments_usecd(
+        g["m_labels"].astype(np.int64), pred, g["m_ptype"].astype(np.int64), g["m_types"].astype(np.int64), w,
+        T.from_numpy(g["m_points"]).cuda())
+    np.testing.assert_array_equal(matching[0][0], g["m_rows"])
+    np.testing.assert_array_equal(matching[0][1], g["m_cols"])
+    np.testing.assert_allclose([s_iou, p_iou, recall], g["m_result"], rtol=1e-6)
+    assert 0 < recall <= 1 and len(pairs) > 0

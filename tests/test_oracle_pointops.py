@@ -51,3 +51,23 @@ def test_fps_ball_query_three_nn_properties():
     np.testing.assert_allclose(out[0, :, 0], pts[0][:, i3[0, 0]].mean(1), rtol=1e-5)
     g = po.group_points(pts, bq)
     assert g.shape == (2, 4, 10, 8) and g[1, 2, 3, 4] == pts[1, 2, bq[1, 3, 4]]
+
+
+def test_chamfer_oracle_matches_reference_twin(golden):
+    """F-CD: values and autograd gradients of the reference's own chamfer_distance (src/utils.py:273-296), captured by
+    tests/golden/make_golden.py gen_chamfer."""
+    g = golden("f_chamfer")
+    a, b = g["a"], g["b"]
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+    d1, i1 = po.chamfer_nn(a, b)
+    d2, i2 = po.chamfer_nn(b, a)
+    np.testing.assert_allclose(np.mean(d1.mean(1) + d2.mean(1)) / 2, g["cd"], rtol=1e-5)
+    np.testing.assert_allclose(d1.mean(), g["side0"], rtol=1e-5)
+    np.testing.assert_allclose(d2.mean(), g["side1"], rtol=1e-5)
+    sq = lambda d: np.sqrt(np.maximum(d, 1e-5))
+    np.testing.assert_allclose(np.mean(sq(d1).mean(1) + sq(d2).mean(1)) / 2, g["cd_sqrt"], rtol=1e-5)
+    g1 = np.full(d1.shape, 1.0 / (2 * B * n), np.float32)
+    g2 = np.full(d2.shape, 1.0 / (2 * B * m), np.float32)
+    ga, gb = po.chamfer_grad(a, b, g1, i1, g2, i2)
+    np.testing.assert_allclose(ga, g["grad_a"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(gb, g["grad_b"], rtol=1e-4, atol=1e-9)

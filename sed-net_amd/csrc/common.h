@@ -35,6 +35,30 @@ __device__ __forceinline__ float sortable_f32(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// Per-row squared norm, sequential over channels with the products rounded before the adds
+// (PointNet.py:77  xx = torch.sum(x ** 2, dim=1)). One thread = one row (256 rows per block); the rows are staged
+// through LDS in 32-channel slices so that global reads are coalesced (a thread walking its own 256-byte row re-fetches
+// every line ~20 times through L1). Same additions in the same order as the plain per-thread loop.
+__device__ __forceinline__ void sed_row_sqnorm_block(const float* __restrict__ X, float* __restrict__ xx, int rows,
+                                                     int D, int C, float* tile /* [256 * 33] */) {
+    const int r0 = blockIdx.x * 256, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        for (int i = tid; i < 256 * 32; i += 256) {
+            const int row = i >> 5, c = i & 31;
+            tile[row * 33 + c] = (r0 + row < rows && c0 + c < C) ? X[(size_t)(r0 + row) * D + c0 + c] : 0.f;
+        }
+        __syncthreads();
+        const int cn = C - c0 < 32 ? C - c0 : 32;
+        for (int c = 0; c < cn; ++c) {
+            const float v = tile[tid * 33 + c];
+            acc = __fadd_rn(acc, __fmul_rn(v, v));
+        }
+        __syncthreads();
+    }
+    if (r0 + tid < rows) xx[r0 + tid] = acc;
+}
+
 static inline int sed_pad_dim(int d) {      // feature width the MFMA kernels are instantiated for
     if (d <= 32) return 32;
     if (d <= 64) return 64;

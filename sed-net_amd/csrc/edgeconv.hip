@@ -39,7 +39,14 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     double* red = (double*)(smem + 2 * C * 64);   // [4 waves][2 tiles][2]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y, slab = blockIdx.z, o0 = slab * 64;
+    // XCD-aware block mapping (speed only): consecutive workgroup ids are dealt round-robin to the 8 XCDs; remapping
+    // gives each XCD a contiguous range = whole clouds, so the neighbour gathers of a cloud hit ONE private L2.
+    const int nbx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * nbx + blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int cloud = wgid / nbx, bxi = wgid - cloud * nbx;
+    const int slab = blockIdx.z, o0 = slab * 64;
     for (int i = tid; i < C * 64; i += 256) {
         const int c = i >> 6, o = i & 63;
         w1[i] = W1t[(size_t)c * Cout + o0 + o];
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     }
     __syncthreads();
 
-    const int p0 = blockIdx.x * 128 + wave * 32;
+    const int p0 = bxi * 128 + wave * 32;
     const int p = p0 + li;
     const int pc = p < N ? p : N - 1;
     const float* xb = x + (size_t)cloud * N * ldx;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
         double a = 0.0;
         for (int w = 0; w < 4; ++w) a += red[(w * 2 + t) * 2 + which];
         const int ntile = Cout / 32;
-        part[(((size_t)cloud * gridDim.x + blockIdx.x) * ntile + slab * 2 + t) * 2 + which] = a;
+        part[(((size_t)cloud * gridDim.x + bxi) * ntile + slab * 2 + t) * 2 + which] = a;
     }
 }
 

@@ -302,13 +302,10 @@ Ws carve(void* ws, int B, int N) {
     w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
     return w;
 }
-__global__ void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows, int D, int C) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    const float* x = X + (size_t)i * D;
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(x[c], x[c]));     // xx = sum(x ** 2)  (PointNet.py:77)
-    xx[i] = acc;
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows,
+                                                     int D, int C) {
+    __shared__ float tile[256 * 33];
+    sed_row_sqnorm_block(X, xx, rows, D, C, tile);
 }
 template <int NT, int M>
 void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {

@@ -121,15 +121,11 @@ __global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restri
     }
 }
 
-// per-row squared norm, sequential over channels, products rounded before the adds
-// (PointNet.py:77  xx = torch.sum(x ** 2, dim=1))
-__global__ void row_sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows, int D, int C) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    const float* x = X + (size_t)i * D;
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(x[c], x[c]));
-    xx[i] = acc;
+// per-row squared norm (common.h: sequential over channels, products rounded before the adds)
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx,
+                                                         int rows, int D, int C) {
+    __shared__ float tile[256 * 33];
+    sed_row_sqnorm_block(X, xx, rows, D, C, tile);
 }
 
 // first-layer metric on xyz + normals, channel-major input x6 [B,6,N]

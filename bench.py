@@ -179,7 +179,8 @@ def main():
             "value": round(total_clouds / elapsed, 3), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 64 x 10k-point clouds per GPU, k=20, full HIP path "
+            "config": {"workload": ("BASELINE configs[2]: " if (B, N, args.k) == (64, 10000, 20) else "") +
+                                   f"{B} x {N}-point clouds per GPU, k={args.k}, full HIP path "
                                    "(2 SED-Net forwards + guarded mean-shift + primitive LSQ fits + residuals)",
                        "clouds_per_gpu": B, "points": N, "k": args.k, "ms_iterations": args.iterations,
                        "embedding_dim": 128, "weights": "closed-form synthetic", "parallelism": f"cloud-shard x{world}",

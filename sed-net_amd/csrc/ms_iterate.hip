@@ -191,9 +191,16 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restr
 //   * 64 keys per LDS stage (two 32-key sub-tiles per barrier): half the barriers / staging bookkeeping per MFMA;
 //   * feature <-> register map d = 4 * ((r&3) + 8(r>>2) + 4 hi) + c for register (c, r) of Q / O, which makes the
 //     second product's operand read a ds_read_b128 too (16 + 16 LDS reads per sub-tile instead of 16 + 32).
+//   * SPARSE (opt-in, sed_ms_iterate_sparse_f32): a wave skips the exponentials and the second product of a 32-key
+//     sub-tile when every exponent argument of its 32 x 32 block is below `skip_below` (e.g. -30: all 1024 kernel
+//     weights <= 9.4e-14). The dropped weights sum to <= N e^skip_below relative to a row sum >= 1 (the self weight),
+//     i.e. <= 1e-9 at N = 10 000 -- 60 x below fp32 resolution. Pays when rows are ordered so that tiles are
+//     cluster-pure (the host sorts by nearest pivot first); on unstructured data nothing is skipped.
+template <bool SPARSE>
 __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __restrict__ X,
                                                                  float* __restrict__ newX,
-                                                                 const float* __restrict__ bw, int N, int iters) {
+                                                                 const float* __restrict__ bw, int N, int iters,
+                                                                 float skip_below) {
     constexpr int D = 128, LDX = 132, C4 = 32, KT = 64;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // [2][KT * LDX]
     const int tid = threadIdx.x;
@@ -271,12 +278,27 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __
                         for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[c][r], s);
                     }
                     float p[16];
+                    if (SPARSE) {
+                        float amax = -3.0e38f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float dist = 2.0f - 2.0f * s[r];
-                        float a = dist * neg_half_inv_b2;
-                        a = fminf(fmaxf(a, -75.0f), 75.0f);
-                        p[r] = exp_compensated(a);
+                        for (int r = 0; r < 16; ++r) {
+                            const float dist = 2.0f - 2.0f * s[r];
+                            float a = dist * neg_half_inv_b2;
+                            a = fminf(fmaxf(a, -75.0f), 75.0f);
+                            p[r] = a;
+                            amax = fmaxf(amax, a);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(amax >= skip_below) == 0) continue;      // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) p[r] = exp_compensated(p[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float dist = 2.0f - 2.0f * s[r];
+                            float a = dist * neg_half_inv_b2;
+                            a = fminf(fmaxf(a, -75.0f), 75.0f);
+                            p[r] = exp_compensated(a);
+                        }
                     }
                     if (key0 + 32 > N) {
 #pragma unroll
@@ -857,16 +879,37 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
             constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);          // 66 KiB of dynamic LDS: opt in once
             static bool attr_set = false;
             if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel,
+                hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, sm);
                 if (e != hipSuccess) return (int)e;
                 attr_set = true;
             }
-            ms_iterate_d128_kernel<<<grid, block, sm, stream>>>(X, newX, bw, N, iters);
+            ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f);
             break;
         }
         case 5: ms_iterate_kernel<5><<<grid, block, 0, stream>>>(X, newX, bw, N, iters); break;
     }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// Opt-in block-sparse schedule of the batched d = 128 kernel: identical arithmetic, except that a wave skips a 32 x 32
+// (keys x queries) block whose exponent arguments are all below `skip_below` (< 0; -30 drops weights <= 9.4e-14, a
+// relative perturbation of the row sums <= N e^-30). The caller orders the rows so that blocks are cluster-pure
+// (sednet_hip.ops.ms_iterate_sparse sorts by nearest pivot and restores the order). src/mean_shift.py:45-79.
+extern "C" int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                                         float skip_below, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f)) return SED_EINVAL;
+    if (d != 128) return SED_EUNSUPPORTED;
+    constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ms_iterate_d128_kernel<true><<<dim3((N + 127) / 128, B), 256, sm, stream>>>(X, newX, bw, N, iters, skip_below);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

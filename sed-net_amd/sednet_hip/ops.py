@@ -128,9 +128,43 @@ def ms_bandwidth(X, K, min_bw=0.003):
     return bw
 
 
+MS_SPARSE_SKIP = None      # e.g. -30.0: opt into the block-sparse schedule (ms_iterate_sparse) for d = 128
+
+
+def ms_pivot_order(X, n_pivots=64):
+    """Row order that makes 32-row blocks cluster-pure: group every row with its nearest of `n_pivots` evenly strided
+    rows (largest dot product on the unit sphere), stable-sort by group. -> order [B,N] int64."""
+    B, N, _ = X.shape
+    piv = X[:, torch.linspace(0, N - 1, min(n_pivots, N), device=X.device).long()]
+    grp = torch.bmm(X, piv.transpose(1, 2)).argmax(2)
+    return torch.sort(grp, dim=1, stable=True)[1]
+
+
+def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64):
+    """ms_iterate with the block-sparse schedule (sed_ms_iterate_sparse_f32): rows are sorted by nearest pivot, blocks
+    whose kernel weights are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the
+    result is returned in the caller's row order. d = 128 only."""
+    B, N, D = X.shape
+    order = ms_pivot_order(X, n_pivots)
+    gidx = order.unsqueeze(-1).expand(B, N, D)
+    Xs = torch.gather(X, 1, gidx).contiguous()
+    outs = torch.empty_like(Xs)
+    if TIMERS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below), stream()),
+          "ms_iterate_sparse")
+    if TIMERS is not None:
+        ev1.record()
+        TIMERS.append(("ms_iterate_sparse", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
+    return torch.empty_like(outs).scatter_(1, gidx, outs)
+
+
 def ms_iterate(X, bw, iters):
     """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79)."""
     B, N, D = X.shape
+    if MS_SPARSE_SKIP is not None and D == 128 and iters > 0:
+        return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
     out = torch.empty_like(X)
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

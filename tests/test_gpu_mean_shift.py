@@ -155,6 +155,40 @@ def test_chunked_schedule_other_widths(T):
         np.testing.assert_allclose(res["batched"][rows], ref, atol=3e-5)
 
 
+def test_block_sparse_schedule(T):
+    """Opt-in sparse schedule (rows sorted by nearest pivot, blocks with all weights <= e^-30 skipped): same rows in the
+    caller's order within summation-order noise, identical labels; nothing to skip on unstructured data; argument checks."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import lib, ptr, stream
+    from src.mean_shift import MeanShift
+    Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=10 + c, sigma=0.01, seed=60 + c)[0]
+                   for c in range(3)])
+    X = dev(T, Xs)
+    bw = ops.ms_bandwidth(X, 150, 0.003)
+    dense = ops.ms_iterate(X, bw, 50)
+    sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0)
+    np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5)
+    order = ops.ms_pivot_order(X)
+    assert (T.sort(order, 1)[0] == T.arange(9973, device="cuda")[None]).all()          # a permutation per cloud
+    ms = MeanShift()
+    ref = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
+    try:
+        ops.MS_SPARSE_SKIP = -30.0
+        got = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
+    finally:
+        ops.MS_SPARSE_SKIP = None
+    for b in range(3):
+        np.testing.assert_array_equal(canon(got[b]), canon(ref[b]))
+    Xr = T.nn.functional.normalize(T.randn(2, 3000, 128, generator=T.Generator().manual_seed(1)), dim=2).cuda()
+    bwr = ops.ms_bandwidth(Xr, 45, 0.003)
+    np.testing.assert_allclose(ops.ms_iterate_sparse(Xr, bwr, 5).cpu().numpy(), ops.ms_iterate(Xr, bwr, 5).cpu().numpy(),
+                               atol=2e-5)
+    out = T.empty_like(Xr)
+    assert lib.sed_ms_iterate_sparse_f32(2, 3000, 128, 5, ptr(bwr), ptr(Xr), ptr(out), 0.0, stream()) == -1
+    X64 = T.zeros(1, 64, 64, device="cuda")
+    assert lib.sed_ms_iterate_sparse_f32(1, 64, 64, 1, ptr(bwr), ptr(X64), ptr(T.empty_like(X64)), -30.0, stream()) == -2
+
+
 def test_guard_loop_matches_golden(T, golden):
     """> 49 clusters on the first passes -> quantile *= 1.2 until the twin clusters merge
     (generate_predictions_aug.py:25-35)."""

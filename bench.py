@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-k64", action="store_true", help="skip the extra k = 64 measurement")
     return ap.parse_args()
 
 
@@ -191,6 +192,20 @@ def main():
                          "flops_per_launch": flops_per_cloud * float(np.mean(it_clouds))},
         }
         line["stages_ms_per_step"] = {k_: round(v, 2) for k_, v in stage_ms.items()}
+        if world == 1 and args.k != 64 and not args.no_k64:
+            # also report the reference's default neighbourhood size k = 64 (same clouds, same path)
+            m64 = build_models(64, dev)
+            pipe64 = SegmentationPipeline(m64[0], m64[1], quantile=0.015, iterations=args.iterations)
+            pipe64(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe64(x)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            line["k64"] = {"value": round(B * args.steps / el, 3), "unit": "clouds/s",
+                           "ms_per_step": round(el / args.steps * 1e3, 2),
+                           "note": "same workload at the reference's default k = 64 (generate_predictions_aug.py:63)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

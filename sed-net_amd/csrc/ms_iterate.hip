@@ -260,9 +260,14 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
         float rsum = 0.f;
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const bool last = (it == iters - 1) && (tile == ntiles - 1);
-            if (!last) stage_load(tile + 1 == ntiles ? 0 : tile + 1);
+        // key sweep alternates direction (forward on even iterations, backward on odd ones): X (5 MB per cloud) is a
+        // little larger than an XCD's L2 (4 MB), so a cyclic sweep would miss on every line; after the turn-around the
+        // most recently streamed ~3/4 of X are still resident
+        const bool fwd = (it & 1) == 0;
+        for (int j = 0; j < ntiles; ++j) {
+            const int tile = fwd ? j : ntiles - 1 - j;
+            const bool last = (it == iters - 1) && (j == ntiles - 1);
+            if (!last) stage_load(j + 1 == ntiles ? tile : (fwd ? tile + 1 : tile - 1));
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const float* xt = lds_dyn + cur * KT * LDX + sub * 32 * LDX;

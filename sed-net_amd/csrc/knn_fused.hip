@@ -34,10 +34,11 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     __shared__ float xxs[2][32];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y;
+    int bxi;
+    const int cloud = sed_xcd_cloud_block(&bxi);
     const float* Xc = X + (size_t)cloud * N * D;
     const float* xxc = xx + (size_t)cloud * N;
-    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow = bxi * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int ntiles = (N + 31) >> 5;
 

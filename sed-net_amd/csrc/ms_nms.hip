@@ -23,10 +23,11 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
     constexpr int C4 = D / 4;
     __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y;
+    int bxi;
+    const int cloud = sed_xcd_cloud_block(&bxi);
     const float* Cc = C + (size_t)cloud * N * D;
     const float* Xc = X + (size_t)cloud * N * D;
-    const int prow = blockIdx.x * 128 + wave * 32 + li;
+    const int prow = bxi * 128 + wave * 32 + li;
     const int prow_c = prow < N ? prow : N - 1;
     const int ntiles = (N + 31) >> 5;
 

@@ -29,11 +29,12 @@ __global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restri
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y;
+    int bxi;
+    const int cloud = sed_xcd_cloud_block(&bxi);
     const float* Xc = X + (size_t)cloud * N * D;
     const float* xxc = xx ? xx + (size_t)cloud * N : nullptr;
     float* Dc = Dout + (size_t)cloud * N * ldD;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = bxi * 128 + wave * 32;
     const int qrow = q0 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int ntiles = (N + 31) >> 5;

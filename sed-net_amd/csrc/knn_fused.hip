@@ -96,8 +96,13 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     stage_store(0);
     __syncthreads();
     int cur = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        if (tile + 1 < ntiles) stage_load(tile + 1);
+    // Sweep 1 only needs SOME valid upper bound of the k-th smallest score: on large clouds it visits every other key
+    // tile (any 32 M distinct row elements bound the k-th smallest from above); sweep 2 then collects ~2x as many
+    // candidates and the selection stays exact. Only for k <= 32, where 2x the candidates (~2.5 k per query, half per
+    // lane) stay far below the list capacity; larger k keep the full first sweep.
+    const int tstep = (PASS == 1 && N >= 4096 && k <= 32) ? 2 : 1;
+    for (int tile = 0; tile < ntiles; tile += tstep) {
+        if (tile + tstep < ntiles) stage_load(tile + tstep);
         const float* xt = lds[cur];
         f32x16 s;
 #pragma unroll
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
                 }
             }
         }
-        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        if (tile + tstep < ntiles) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -199,9 +204,12 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     };
     stage(0, 0);
     __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int cur = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, cur ^ 1);
+    // sweep 1 on every other key tile for small k on large clouds (see knn_sweep_kernel)
+    const int tstep = (PASS == 1 && N >= 4096 && k <= 32) ? 2 : 1;
+    int cur = 1;
+    for (int tile = 0; tile < ntiles; tile += tstep) {
+        cur ^= 1;
+        if (tile + tstep < ntiles) stage(tile + tstep, cur ^ 1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const float* kq = ks[cur][r];

@@ -104,3 +104,29 @@ def test_fused_knn_overflow_falls_back_to_exact_path(T):
     np.testing.assert_array_equal(a, b)                             # same scores, same tie rule: bit-identical
     c_fused = knn_points_normals(dev(T, x6), 20, 20).cpu().numpy()
     np.testing.assert_array_equal(c_fused, c_exact)
+
+
+@pytest.mark.parametrize("k", [20, 32, 33])
+def test_subsampled_first_sweep_stays_exact(T, k):
+    """Clouds of >= 4096 points with k <= 32 take the first (threshold) sweep over every other key tile; the selection
+    must stay bit-identical to the exact materialised path, also with near-duplicate rows and with ordered input (all the
+    visited tiles far from some queries). k = 33 keeps the full first sweep."""
+    from sednet_hip import ops
+    rng = np.random.default_rng(k)
+    N, C = 6000, 64
+    x = rng.normal(size=(2, N, C)).astype(np.float32)
+    x[0, 1000:1040] = x[0, 1000] + 1e-4 * rng.normal(size=(40, C)).astype(np.float32)      # a tight clump
+    order = np.argsort(x[1, :, 0])                                                            # cloud 1 sorted along a feature
+    x[1] = x[1, order]
+    X = T.from_numpy(x).cuda()
+    try:
+        ops.FUSED_STATS.update(fused=0, fallback=0)
+        ops.FUSED_KNN = True
+        a = ops.knn_features(X, k, C)
+        fused = dict(ops.FUSED_STATS)
+        ops.FUSED_KNN = False
+        b = ops.knn_features(X, k, C)
+    finally:
+        ops.FUSED_KNN = True
+    assert T.equal(a, b)
+    assert fused["fused"] == 1 and fused["fallback"] == 0

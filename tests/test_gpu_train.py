@@ -26,7 +26,8 @@ def close(got, ref, rel, msg=""):
     np.testing.assert_allclose(got, ref, rtol=0, atol=rel * scale, err_msg=msg)
 
 
-@pytest.mark.parametrize("C,Cout,N,k,B", [(64, 64, 300, 12, 2), (64, 128, 257, 20, 1), (6, 64, 200, 9, 2)])
+@pytest.mark.parametrize("C,Cout,N,k,B", [(64, 64, 300, 12, 2), (64, 128, 257, 20, 1), (6, 64, 200, 9, 2), (64, 128, 150, 64, 1),
+                                          (6, 64, 130, 64, 1)])
 def test_edgeconv_backward_matches_autograd(T, C, Cout, N, k, B):
     import torch.nn.functional as F
     from oracle import train as ot

@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restr
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
-    const int cloud = blockIdx.y;
+    int bxi;
+    const int cloud = sed_xcd_cloud_block(&bxi);          // whole clouds per XCD (common.h)
     const float* Xc = X + (size_t)cloud * N * D;
-    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const int qrow = bxi * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
 
     const float b = bw[cloud];
@@ -105,9 +106,12 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
         float rsum = 0.f;
 
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const bool last = (it == iters - 1) && (tile == ntiles - 1);
-            if (!last) stage_load(tile + 1 == ntiles ? 0 : tile + 1);
+        // key sweep alternates direction every iteration (L2 re-use after the turn-around, see the D = 128 kernel)
+        const bool fwd = (it & 1) == 0;
+        for (int j = 0; j < ntiles; ++j) {
+            const int tile = fwd ? j : ntiles - 1 - j;
+            const bool last = (it == iters - 1) && (j == ntiles - 1);
+            if (!last) stage_load(j + 1 == ntiles ? tile : (fwd ? tile + 1 : tile - 1));
 
             const float* xt = lds[cur];
             // ---- S^T = X_tile . Q^T  (keys on rows, queries on lanes)

@@ -65,6 +65,14 @@ int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx
 /* ---- mean-shift clustering --------------------------------------------------------------------------- */
 /* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */
 int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, float* bw, sed_stream_t stream);
+/* K-th smallest (1-based, self included) of 2 - 2 x_i.x_j per row WITHOUT the N x N matrix (two MFMA sweeps + short
+ * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128}, K <= sed_ms_kth_fused_max_k().
+ * *overflow (device int) becomes 1 if a candidate list overflowed: kth is then invalid, use the materialised path.
+ * src/mean_shift.py:115-137 (compute_bandwidth: dist = 2 - 2 X X^T, topk(K)). */
+int sed_ms_kth_fused_max_k(void);
+size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
+int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
+                         int* overflow, sed_stream_t stream);
 /* `iters` gaussian mean-shift iterations on unit rows, X [B,N,d] -> newX [B,N,d]; bw [B] on device.
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,

@@ -1,0 +1,226 @@
+// Fused K-th nearest distance per row for the mean-shift bandwidth, without materialising the N x N distance matrix.
+//
+// Replaces /root/reference/src/mean_shift.py:115-137 (compute_bandwidth): the reference builds dist = 2 - 2 X X^T
+// (400 MB per 10k-point cloud) and takes topk(K) per row; the materialised path here (pairwise.hip + select.hip) writes
+// and re-reads that matrix. This file applies the two-sweep scheme of knn_fused.hip to the K-th VALUE (K = 150 at the
+// script's quantile):
+//   sweep 1: per query, the keys a lane sees fall into 32 buckets (2 lanes x 16 accumulator registers); every bucket
+//            keeps its M = 8 smallest distances. Those 256 values are distinct row elements, so their K-th smallest T
+//            bounds the row's K-th smallest from above (K <= 160). On clouds of >= 4096 points the sweep visits every
+//            other key tile (any 256 distinct elements give a valid bound).
+//   sweep 2: recomputes the distances (same instructions => same bits) and appends the ~2 K values <= T to lane-private
+//            lists (plain stores).
+//   finalize: one wave per query bisects its <= 512 candidates for the exact K-th smallest.
+// Distances are 2 - 2 s with s the same fp32 MFMA chain as pair_dist_kernel<NT, MODE_MS>, so the K-th values are
+// bit-identical to the materialised path. A list overflow raises a flag and the caller re-runs the materialised path.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 8;             // minima kept per bucket in sweep 1
+constexpr int CAPK = 256;         // candidates per lane (two lanes per query)
+constexpr int KMAX = 160;
+
+template <int NT, int PASS>
+__global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, int N, int K,
+                                                              uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ lists,
+                                                              int* __restrict__ counts, int* __restrict__ overflow) {
+    constexpr int D = 32 * NT;
+    constexpr int LDX = D + 4;
+    constexpr int C4 = D / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    int bxi;
+    const int cloud = sed_xcd_cloud_block(&bxi);
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int qrow = bxi * 128 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int ntiles = (N + 31) >> 5;
+
+    float q[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+        }
+    f32x4 stage[NT];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            const int key = tile * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
+            stage[u] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / C4, c4 = i % C4;
+            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+        }
+    };
+
+    uint32_t bm[PASS == 1 ? BM : 1][16];
+    if (PASS == 1) {
+#pragma unroll
+        for (int i = 0; i < BM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bm[i][r] = 0xFFFFFFFFu;
+    }
+    uint32_t T = 0;
+    int cnt = 0;
+    uint32_t* mylist = nullptr;
+    if (PASS == 2) {
+        T = Tbuf[(size_t)cloud * N + qrow_c];
+        mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPK;
+    }
+
+    const int tstep = (PASS == 1 && N >= 4096) ? 2 : 1;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; tile += tstep) {
+        if (tile + tstep < ntiles) stage_load(tile + tstep);
+        const float* xt = lds[cur];
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
+            }
+        const bool ragged = (tile == ntiles - 1) && (N & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dv = 2.0f - 2.0f * s[r];                                         // mean_shift.py:128
+            uint32_t key = f32_sortable(dv);
+            if (ragged && tile * 32 + mfma_row(r, hi) >= N) key = 0xFFFFFFFFu;
+            if (PASS == 1) {
+#pragma unroll
+                for (int i = 0; i < BM; ++i) {
+                    const uint32_t lo_ = min(bm[i][r], key);
+                    key = max(bm[i][r], key);
+                    bm[i][r] = lo_;
+                }
+            } else {
+                if (key <= T && key != 0xFFFFFFFFu) {
+                    if (cnt < CAPK) mylist[cnt] = key;
+                    ++cnt;
+                }
+            }
+        }
+        if (tile + tstep < ntiles) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (PASS == 1) {
+        // K-th smallest of this query's 32 * BM bucket values (this lane's + the partner lane's)
+        uint32_t lo = 0, hiv = 0xFFFFFFFFu;
+        for (int it = 0; it < 32; ++it) {
+            const uint32_t mid = lo + ((hiv - lo) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c += bm[i][r] <= mid ? 1 : 0;
+            c += __shfl_xor(c, 32, 64);
+            if (lo < hiv) { if (c >= K) hiv = mid; else lo = mid + 1; }
+        }
+        if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
+    } else if (qrow < N) {
+        counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
+        if (cnt > CAPK) *overflow = 1;
+    }
+}
+
+// one wave per query: exact K-th smallest of its candidates (<= 2 CAPK keys). grid ceil(rows / 4), block 256
+__global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __restrict__ lists,
+                                                              const int* __restrict__ counts, int K, size_t rows,
+                                                              float* __restrict__ kth) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int c0 = min(counts[row * 2], CAPK), c1 = min(counts[row * 2 + 1], CAPK);
+    const uint32_t* l0 = lists + row * 2 * CAPK;
+    uint32_t v[2 * CAPK / 64];
+#pragma unroll
+    for (int u = 0; u < 2 * CAPK / 64; ++u) {
+        const int i = lane + 64 * u;                  // 0 .. 2 CAPK - 1: first half = lane-0 list, second = lane-1 list
+        const bool ok = i < CAPK ? i < c0 : i - CAPK < c1;
+        v[u] = ok ? l0[i] : 0xFFFFFFFFu;
+    }
+    uint32_t lo = 0, hiv = 0xFFFFFFFEu;
+    for (int it = 0; it < 32; ++it) {
+        const uint32_t mid = lo + ((hiv - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 2 * CAPK / 64; ++u) c += v[u] <= mid ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (lo < hiv) { if (c >= K) hiv = mid; else lo = mid + 1; }
+    }
+    if (lane == 0) kth[row] = sortable_f32(lo);
+}
+
+struct KWs { uint32_t* T; int* counts; uint32_t* lists; };
+KWs kcarve(void* ws, int B, int N) {
+    const size_t bn = (size_t)B * N;
+    KWs w;
+    w.T = (uint32_t*)ws;
+    w.counts = (int*)(w.T + bn);
+    w.lists = (uint32_t*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
+    return w;
+}
+
+template <int NT>
+void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, hipStream_t s) {
+    const dim3 grid((N + 127) / 128, B);
+    ms_kth_sweep_kernel<NT, 1><<<grid, 256, 0, s>>>(X, N, K, w.T, w.lists, w.counts, overflow);
+    ms_kth_sweep_kernel<NT, 2><<<grid, 256, 0, s>>>(X, N, K, w.T, w.lists, w.counts, overflow);
+}
+
+}  // namespace
+
+extern "C" int sed_ms_kth_fused_max_k(void) { return KMAX; }
+
+extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
+    const size_t bn = (size_t)B * N;
+    return bn * sizeof(uint32_t) + bn * 2 * sizeof(int) + bn * 2 * CAPK * sizeof(uint32_t) + 256;
+}
+
+// X [B,N,d] unit rows, d in {32, 64, 96, 128} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
+// over j, bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32. *overflow (device int, zeroed here) becomes 1 if a
+// candidate list overflowed: kth is then invalid and the caller must use the materialised path.
+extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
+                                    int* overflow, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
+    if (d % 32 != 0 || d < 32 || d > 128 || K > KMAX) return SED_EUNSUPPORTED;
+    if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
+    const KWs w = kcarve(ws, B, N);
+    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    switch (d / 32) {
+        case 1: launch_kth<1>(B, X, w, N, K, overflow, stream); break;
+        case 2: launch_kth<2>(B, X, w, N, K, overflow, stream); break;
+        case 3: launch_kth<3>(B, X, w, N, K, overflow, stream); break;
+        default: launch_kth<4>(B, X, w, N, K, overflow, stream); break;
+    }
+    SED_LAUNCH_CHECK();
+    const size_t rows = (size_t)B * N;
+    ms_kth_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, K, rows, kth);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}

@@ -118,12 +118,23 @@ def ms_bandwidth(X, K, min_bw=0.003):
         raise RuntimeError(f"selected index k out of range (K={K}, rows={N})")   # torch.topk's error in the reference
     kth = torch.empty((B, N), dtype=torch.float32, device=X.device)
     bw = torch.empty((B,), dtype=torch.float32, device=X.device)
-    chunks, step = _cloud_chunks(B, N)
-    ws = _pair_ws(step, N, X.device)
-    for b0, b1 in chunks:
-        nb = b1 - b0
-        check(lib.sed_pairdist_ms_f32(nb, N, D, ptr(X[b0:b1]), ptr(ws), _ld(N), stream()), "pairdist_ms")
-        check(lib.sed_row_kth_f32(nb, N, _ld(N), K, ptr(ws), ptr(kth[b0:b1]), stream()), "row_kth")
+    done = False
+    # many clouds: two MFMA sweeps + candidate lists, no N x N matrix (bandwidth_fused.hip). A few clouds leave most CUs
+    # idle in the sweeps; there the materialised path below is the faster one.
+    if FUSED_KNN and D <= 128 and K <= lib.sed_ms_kth_fused_max_k() and B * ((N + 127) // 128) >= 512:
+        nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
+        flag = torch.empty((1,), dtype=torch.int32, device=X.device)
+        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), stream()), "ms_kth_fused")
+        done = int(flag.item()) == 0
+        FUSED_STATS["fused" if done else "fallback"] += 1
+    if not done:
+        chunks, step = _cloud_chunks(B, N)
+        ws = _pair_ws(step, N, X.device)
+        for b0, b1 in chunks:
+            nb = b1 - b0
+            check(lib.sed_pairdist_ms_f32(nb, N, D, ptr(X[b0:b1]), ptr(ws), _ld(N), stream()), "pairdist_ms")
+            check(lib.sed_row_kth_f32(nb, N, _ld(N), K, ptr(ws), ptr(kth[b0:b1]), stream()), "row_kth")
     check(lib.sed_ms_bandwidth_finalize_f32(B, N, float(min_bw), ptr(kth), ptr(bw), stream()), "bandwidth_finalize")
     return bw
 

@@ -189,6 +189,31 @@ def test_block_sparse_schedule(T):
     assert lib.sed_ms_iterate_sparse_f32(1, 64, 64, 1, ptr(bwr), ptr(X64), ptr(T.empty_like(X64)), -30.0, stream()) == -2
 
 
+@pytest.mark.parametrize("N,d,K,B", [(10000, 128, 150, 6), (4500, 64, 67, 3), (1000, 128, 15, 40), (700, 96, 160, 2)])
+def test_fused_kth_distance_is_bit_identical(T, N, d, K, B):
+    """bandwidth_fused.hip (two sweeps, no N x N matrix) against the materialised pair_dist + row_select path:
+    identical K-th values per row; clustered rows with an exact-duplicate clump; ragged N; subsampled first sweep."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import check, lib, ptr, stream
+    Xs = np.stack([synth.clustered_embedding(N=N, d=d, n_clusters=5 + c, sigma=0.02, seed=80 + c)[0] for c in range(B)])
+    Xs[0, 10:40] = Xs[0, 10]                                            # exact duplicates
+    X = ops.pad_features(dev(T, Xs))
+    D = X.shape[2]
+    kth_f = T.empty((B, N), dtype=T.float32, device="cuda")
+    nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
+    ws = T.empty((nbytes,), dtype=T.uint8, device="cuda")
+    flag = T.empty((1,), dtype=T.int32, device="cuda")
+    check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), stream()), "kth_fused")
+    assert int(flag.item()) == 0
+    ld = (N + 3) // 4 * 4
+    mat = T.empty((B, N, ld), dtype=T.float32, device="cuda")
+    kth_m = T.empty((B, N), dtype=T.float32, device="cuda")
+    check(lib.sed_pairdist_ms_f32(B, N, D, ptr(X), ptr(mat), ld, stream()), "pairdist_ms")
+    check(lib.sed_row_kth_f32(B, N, ld, K, ptr(mat), ptr(kth_m), stream()), "row_kth")
+    assert T.equal(kth_f, kth_m)
+    assert lib.sed_ms_kth_fused_f32(B, N, D, 161, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), stream()) == -2
+
+
 def test_guard_loop_matches_golden(T, golden):
     """> 49 clusters on the first passes -> quantile *= 1.2 until the twin clusters merge
     (generate_predictions_aug.py:25-35)."""

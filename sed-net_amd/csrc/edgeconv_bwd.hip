@@ -63,10 +63,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
                                                               const float* __restrict__ gamma,
                                                               float* __restrict__ dgamma_b, float* __restrict__ dbeta_b,
                                                               float* __restrict__ ak /*[B][G][2]*/) {
-    __shared__ double gsum[64][2];
     const int cloud = blockIdx.x;
-    if (threadIdx.x < 64) { gsum[threadIdx.x][0] = 0.0; gsum[threadIdx.x][1] = 0.0; }
-    __syncthreads();
     const int cpg = C / G;
     for (int c = threadIdx.x; c < C; c += 256) {
         double s1 = 0.0, s2 = 0.0;

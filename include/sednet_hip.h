@@ -90,6 +90,15 @@ int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const
  * by nearest pivot and restores the order); nothing is skipped on unstructured data. */
 int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                               float skip_below, sed_stream_t stream);
+/* Second level of the block-sparse schedule: blocks are skipped BEFORE the first product when a geometric bound proves
+ * that all their weights are <= e^skip_below. Rows sorted by nearest of P pivot rows; row_piv [B,N] = that pivot; per
+ * 32-row tile t: tile_rp[t] = a reference pivot, tile_alpha[t] = max angle (rad) between a row of the tile and it;
+ * piv [B,P,128]; pang [B,P,P] pivot-pivot angles. Each iteration a query measures beta = its angle to its own pivot a;
+ * angle(q, x) >= pang[a][rp[t]] - beta - alpha[t] (triangle inequality on the unit sphere) is compared with
+ * acos(1 + skip_below b^2) + margin. N <= 16 384, d = 128. */
+int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                              float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
+                              const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
 /* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
  * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
  * variant above). 0 = choose by grid size (default), 1 = batched, 2 = split-key, 3 = key-chunked (tests, measurements). */

@@ -142,29 +142,77 @@ def ms_bandwidth(X, K, min_bw=0.003):
 MS_SPARSE_SKIP = None      # e.g. -30.0: opt into the block-sparse schedule (ms_iterate_sparse) for d = 128
 
 
-def ms_pivot_order(X, n_pivots=64):
-    """Row order that makes 32-row blocks cluster-pure: group every row with its nearest of `n_pivots` evenly strided
-    rows (largest dot product on the unit sphere), stable-sort by group. -> order [B,N] int64."""
-    B, N, _ = X.shape
-    piv = X[:, torch.linspace(0, N - 1, min(n_pivots, N), device=X.device).long()]
-    grp = torch.bmm(X, piv.transpose(1, 2)).argmax(2)
-    return torch.sort(grp, dim=1, stable=True)[1]
-
-
-def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64):
-    """ms_iterate with the block-sparse schedule (sed_ms_iterate_sparse_f32): rows are sorted by nearest pivot, blocks
-    whose kernel weights are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the
-    result is returned in the caller's row order. d = 128 only."""
+def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
+    """Row order that makes 32-row blocks cluster-pure. Every row joins its nearest of `n_pivots` farthest-point pivot
+    rows (largest dot product on the unit sphere); pivots closer than `merge_angle` (single linkage) form a super-group, and
+    rows are stable-sorted by (super-group, pivot) so that the pivot groups of one cluster are adjacent.
+    -> (order [B,N] int64, pivots [B,P,D], dots of the SORTED rows with all pivots [B,N,P])."""
     B, N, D = X.shape
-    order = ms_pivot_order(X, n_pivots)
+    P = min(n_pivots, N)
+    # farthest-point pivots (greedy k-centre on the sphere): every cluster gets at least one pivot as long as there are
+    # no more clusters than pivots, so no row is left far from its pivot (a far row would need every block)
+    bidx = torch.arange(B, device=X.device)
+    dots = torch.empty((B, N, P), dtype=torch.float32, device=X.device)
+    pick = torch.zeros((B,), dtype=torch.long, device=X.device)
+    picks = []
+    closest = None
+    for j in range(P):
+        picks.append(pick)
+        dots[:, :, j] = torch.bmm(X, X[bidx, pick].unsqueeze(2)).squeeze(2)
+        closest = dots[:, :, j] if closest is None else torch.maximum(closest, dots[:, :, j])
+        pick = closest.argmin(1)
+    # one k-means step: reference directions = normalised means of the pivot groups (any unit vectors are valid
+    # references; the mean sits in the middle of its group, which tightens every angular bound by about a third)
+    grp = dots.argmax(2)
+    piv = torch.zeros((B, P, D), dtype=torch.float32, device=X.device).scatter_add_(
+        1, grp.unsqueeze(-1).expand(B, N, D), X)
+    piv = torch.nn.functional.normalize(piv, dim=2).contiguous()
+    dots = torch.bmm(X, piv.transpose(1, 2))
+    grp = dots.argmax(2)
+    reach = (torch.bmm(piv, piv.transpose(1, 2)) > float(torch.cos(torch.tensor(merge_angle)))).float()
+    for _ in range(6):                                                        # transitive closure of a 64-node graph
+        reach = (torch.bmm(reach, reach) > 0).float()
+    comp = torch.where(reach > 0, torch.arange(P, device=X.device).view(1, 1, P), P).min(2)[0]     # [B,P] min member
+    key = torch.gather(comp, 1, grp) * P + grp
+    order = torch.sort(key, dim=1, stable=True)[1]
+    return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P))
+
+
+def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3):
+    """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
+    are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
+    caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
+    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only."""
+    B, N, D = X.shape
+    order, piv, sdots = ms_pivot_order(X, n_pivots)
     gidx = order.unsqueeze(-1).expand(B, N, D)
     Xs = torch.gather(X, 1, gidx).contiguous()
     outs = torch.empty_like(Xs)
+    use_bounds = bounds and N <= 16384
+    if use_bounds:
+        P = piv.shape[1]
+        ntile = (N + 31) // 32
+        pad = ntile * 32 - N
+        sd = sdots.clamp(-1.0, 1.0)
+        if pad:
+            sd = torch.nn.functional.pad(sd, (0, 0, 0, pad), value=1.0)
+        worst = sd.view(B, ntile, 32, P).min(2)[0]                           # per tile and pivot: its farthest row
+        best, rp = worst.max(2)                                               # reference pivot = tightest cap over the tile
+        alpha = torch.acos(best).contiguous()
+        pang = torch.acos(torch.bmm(piv, piv.transpose(1, 2)).clamp(-1.0, 1.0)).contiguous()
+        rp32 = rp.int().contiguous()
+        rowp = sdots.argmax(2).int().contiguous()                             # nearest pivot of every (sorted) row
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below), stream()),
-          "ms_iterate_sparse")
+    if use_bounds:
+        check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                            ptr(rowp), ptr(rp32), ptr(alpha), ptr(piv), ptr(pang), P, float(margin),
+                                            stream()),
+              "ms_iterate_bounds")
+    else:
+        check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                            stream()), "ms_iterate_sparse")
     if TIMERS is not None:
         ev1.record()
         TIMERS.append(("ms_iterate_sparse", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))

@@ -166,9 +166,10 @@ def test_block_sparse_schedule(T):
     X = dev(T, Xs)
     bw = ops.ms_bandwidth(X, 150, 0.003)
     dense = ops.ms_iterate(X, bw, 50)
-    sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0)
-    np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5)
-    order = ops.ms_pivot_order(X)
+    for bounds in (False, True):
+        sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0, bounds=bounds)
+        np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5)
+    order = ops.ms_pivot_order(X)[0]
     assert (T.sort(order, 1)[0] == T.arange(9973, device="cuda")[None]).all()          # a permutation per cloud
     ms = MeanShift()
     ref = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
@@ -179,10 +180,16 @@ def test_block_sparse_schedule(T):
         ops.MS_SPARSE_SKIP = None
     for b in range(3):
         np.testing.assert_array_equal(canon(got[b]), canon(ref[b]))
+    # wider clusters (sigma = 0.04: neighbouring clusters overlap in angle, few blocks can be skipped) -- still the same rows
+    Xw = dev(T, np.stack([synth.clustered_embedding(N=5000, d=128, n_clusters=20, sigma=0.04, seed=77)[0]]))
+    bww = ops.ms_bandwidth(Xw, 75, 0.003)
+    np.testing.assert_allclose(ops.ms_iterate_sparse(Xw, bww, 50, -30.0).cpu().numpy(),
+                               ops.ms_iterate(Xw, bww, 50).cpu().numpy(), atol=3e-5)
     Xr = T.nn.functional.normalize(T.randn(2, 3000, 128, generator=T.Generator().manual_seed(1)), dim=2).cuda()
     bwr = ops.ms_bandwidth(Xr, 45, 0.003)
-    np.testing.assert_allclose(ops.ms_iterate_sparse(Xr, bwr, 5).cpu().numpy(), ops.ms_iterate(Xr, bwr, 5).cpu().numpy(),
-                               atol=2e-5)
+    for bounds in (False, True):
+        np.testing.assert_allclose(ops.ms_iterate_sparse(Xr, bwr, 5, bounds=bounds).cpu().numpy(),
+                                   ops.ms_iterate(Xr, bwr, 5).cpu().numpy(), atol=2e-5)
     out = T.empty_like(Xr)
     assert lib.sed_ms_iterate_sparse_f32(2, 3000, 128, 5, ptr(bwr), ptr(Xr), ptr(out), 0.0, stream()) == -1
     X64 = T.zeros(1, 64, 64, device="cuda")

@@ -11,8 +11,10 @@ def t(f):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); return r, (time.perf_counter() - t0) * 1e3
 d, td = t(lambda: ops.ms_iterate(X, bw, 50))
 for skip in (-30.0, -20.0):
-    s, ts = t(lambda: ops.ms_iterate_sparse(X, bw, 50, skip))
-    print(f"skip {skip}: dense {td:.1f} ms, sparse {ts:.1f} ms, max |diff| {(d - s).abs().max().item():.2e}")
+    for bounds in (False, True):
+        s, ts = t(lambda: ops.ms_iterate_sparse(X, bw, 50, skip, bounds=bounds))
+        print(f"skip {skip} bounds {bounds}: dense {td:.1f} ms, sparse {ts:.1f} ms (incl. sort / bounds / unsort), "
+              f"max |diff| {(d - s).abs().max().item():.2e}")
 o, to = t(lambda: ops.ms_pivot_order(X))
 print(f"pivot order {to:.2f} ms")
 # unstructured data: nothing to skip

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Probe: the bench pipeline (64 clouds, closed-form weights) with the block-sparse mean-shift schedule switched on."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sed-net_amd"))
+import numpy as np, torch
+import bench
+from sednet_hip import ops, synth
+from sednet_hip.pipeline import SegmentationPipeline
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x = torch.from_numpy(synth.batch_clouds(B, 10000, seed0=1234)[0]).cuda()
+m_type, m_inst = bench.build_models(20, torch.device("cuda"))
+pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50)
+res = {}
+for mode in (None, -30.0):
+    ops.MS_SPARSE_SKIP = mode
+    out = pipe(x); torch.cuda.synchronize()
+    t0 = time.perf_counter(); out = pipe(x); torch.cuda.synchronize()
+    res[mode] = (time.perf_counter() - t0, out["labels"].cpu().numpy(), out["n_labels"])
+    print("sparse" if mode else "dense ", f"{res[mode][0] * 1e3:.1f} ms per step, {B / res[mode][0]:.1f} clouds/s, clusters per cloud",
+          np.asarray(out["n_labels"].cpu() if hasattr(out["n_labels"], "cpu") else out["n_labels"])[:8])
+ops.MS_SPARSE_SKIP = None
+def canonical_labels(l):                       # relabel by first occurrence
+    _, first, inv = np.unique(l, return_index=True, return_inverse=True)
+    return np.argsort(np.argsort(first))[inv]
+
+
+same = [bool((canonical_labels(res[None][1][b]) == canonical_labels(res[-30.0][1][b])).all()) for b in range(B)]
+print("labels identical in", sum(same), "of", B, "clouds (the closed-form-weight embedding collapses to ~1 cluster whose "
+      "spurious splits hinge on last-ulp noise, so any change of summation order can move them)")

@@ -101,8 +101,15 @@ int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, c
                               const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
 /* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
  * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
- * variant above). 0 = choose by grid size (default), 1 = batched, 2 = split-key, 3 = key-chunked (tests, measurements). */
+ * variant above), and split-fp16 (ms_iterate_f16.hip: the two fp32 products evaluated as 3 fp16 MFMAs each on round-to-
+ * nearest (h, l) splits of the fp32 operands -- dropped terms <= 3 * 2^-24 relative, fp32 accumulation -- needs the
+ * workspace; clouds whose rows are not unit vectors fall back to the fp32 kernel on the device). 0 = choose by size
+ * (default: split-fp16 whenever the workspace is given), 1 = batched, 2 = split-key, 3 = key-chunked, 4 = split-fp16
+ * (tests, measurements). */
 int sed_ms_set_variant(int variant);
+/* split-fp16 schedule: 0 = 64-key stages, one 8-wave workgroup per CU (default); 1 = 32-key stages, two 4-wave
+ * workgroups per CU (measurements). Changes sed_ms_iterate_workspace_bytes. */
+int sed_ms_set_f16_config(int cfg);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
  * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */

@@ -204,7 +204,8 @@ template <bool SPARSE>
 __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __restrict__ X,
                                                                  float* __restrict__ newX,
                                                                  const float* __restrict__ bw, int N, int iters,
-                                                                 float skip_below) {
+                                                                 float skip_below,
+                                                                 const int* __restrict__ only = nullptr) {
     constexpr int D = 128, LDX = 132, C4 = 32, KT = 64;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // [2][KT * LDX]
     const int tid = threadIdx.x;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_d128_kernel(const float* __
     const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
     const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
     const int cloud = wgid / nbx, bx = wgid - cloud * nbx;
+    if (only && !only[cloud]) return;        // fallback pass behind the split-fp16 kernel: flagged clouds only
     const float* Xc = X + (size_t)cloud * N * D;
     const int qrow = bx * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
@@ -790,11 +792,16 @@ int ms_chunks(int N) {
     return S < 2 ? 2 : (S > 32 ? 32 : S);
 }
 
-enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3 };
+enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3, MS_F16 = 4 };
 
-int ms_plan(int B, int N, int d, bool have_ws, int forced) {
+// `have_ws`: a workspace large enough for the key-chunked partials; `have_f16`: one large enough for the split-fp16
+// stage images. The split-fp16 kernel (ms_iterate_f16.hip: 5.3 x less matrix time, fp32-equivalent error) is the
+// default for d = 128 from two clouds' worth of 256-row workgroups; a single small cloud keeps the fp32 schedules.
+int ms_plan(int B, int N, int d, bool have_ws, bool have_f16, int forced) {
     const long W = (long)B * ((N + 127) / 128), W4 = (long)B * ((N + 31) / 32);
     const int S = ms_chunks(N);
+    if (forced == MS_F16) return (d == 128 && have_f16) ? MS_F16 : MS_BATCHED;
+    if (!forced && d == 128 && have_f16 && (B >= 2 || N < 2560)) return MS_F16;
     if (forced == MS_CHUNKED) return (S && have_ws) ? MS_CHUNKED : MS_BATCHED;
     if (forced == MS_SPLITK && d != 128) return MS_BATCHED;
     if (forced) return forced;
@@ -805,19 +812,26 @@ int ms_plan(int B, int N, int d, bool have_ws, int forced) {
     return ck < cb ? MS_SPLITK : MS_BATCHED;
 }
 
-int g_ms_variant = 0;      // 0 = choose by grid size, 1 = batched kernel, 2 = split-key kernel, 3 = key-chunked launches
+int g_ms_variant = 0;      // 0 = choose by size, 1 = batched fp32, 2 = split-key fp32, 3 = key-chunked fp32, 4 = split-fp16
 
 }  // namespace
 
+// ms_iterate_f16.hip
+size_t ms_f16_workspace_bytes(int B, int N);
+int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                  int** flags_out, hipStream_t stream);
+
 extern "C" int sed_ms_set_variant(int variant) {
-    if (variant < 0 || variant > 3) return SED_EINVAL;
+    if (variant < 0 || variant > 4) return SED_EINVAL;
     g_ms_variant = variant;
     return SED_OK;
 }
 
 extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
     if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
-    if (ms_plan(B, N, d, true, g_ms_variant) != MS_CHUNKED) return 0;
+    const int plan = ms_plan(B, N, d, true, true, g_ms_variant);
+    if (plan == MS_F16) return ms_f16_workspace_bytes(B, N);
+    if (plan != MS_CHUNKED) return 0;
     return (size_t)B * N * ms_chunks(N) * (d + 1) * sizeof(float);
 }
 
@@ -838,7 +852,26 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     dim3 grid((N + 127) / 128, B), block(256);
     const int S = ms_chunks(N);
     const size_t need = (size_t)B * N * S * (d + 1) * sizeof(float);
-    const int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, g_ms_variant);
+    const bool have_f16 = iters > 0 && workspace && d == 128 && workspace_bytes >= ms_f16_workspace_bytes(B, N);
+    const int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, g_ms_variant);
+    if (plan == MS_F16) {
+        int* flags = nullptr;
+        const int rc = ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, stream);
+        if (rc != SED_OK) return rc;
+        // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
+        // its workgroups return at once for every other cloud
+        constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
+        static bool attr_fb = false;
+        if (!attr_fb) {
+            hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+            if (e != hipSuccess) return (int)e;
+            attr_fb = true;
+        }
+        ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
     if (plan == MS_CHUNKED) {
         float* partO = (float*)workspace;
         float* partS = partO + (size_t)B * N * S * d;

@@ -1,0 +1,346 @@
+// Mean-shift iterations (d = 128) on the fp16 matrix pipe with fp32-equivalent arithmetic: split-fp16 emulation.
+//
+// Same mathematics as ms_iterate.hip (/root/reference/src/mean_shift.py:56-77, guard.py:7-9); what changes is how the
+// two fp32 products  S = Q X^T  and  O = P X  are evaluated.  v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate
+// (157 TFLOP/s); v_mfma_f32_32x32x16_f16 is 16 x faster.  Every fp32 operand v is split (round to nearest) into
+//     v * 2^s = h + l + e,   h = fp16(v 2^s),  l = fp16(v 2^s - h),  |e| <= 2^-24 |v 2^s|      (two 11-bit signed digits)
+// and a product a.b is evaluated as  l_a h_b + h_a l_b + h_a h_b : three fp16 MFMAs (products of two fp16 values are
+// exact in fp32, accumulation is the MFMA's fp32 accumulator).  What is dropped -- l_a l_b and the e terms -- is
+// <= 3 * 2^-24 relative to |a||b| per product, i.e. the size of ONE fp32 rounding, whereas the fp32 fma chain it replaces
+// rounds 128 (S) / 10 000 (O) times.  3 fp16 MFMAs instead of 16 fp32-rate units: 5.3 x less matrix time.
+// Scales: X and Q by 2^11 (unit rows: |x| <= 1 -> |h| <= 2048, l stays in fp16's normal range for |x| >= 2^-14),
+// P by 2^14 (weights <= 1; anything below 2^-38 flushes to 0: a relative change of a row sum (>= ~1) of <= N 2^-39).
+// The exponent argument needs p 2^14 <= 65504, i.e. rows of norm <= 1: ms_split_kernel measures the row norms and
+// flags clouds that violate (|x|^2 - 1) / b^2 <= 1; flagged clouds are skipped here and done by the exact fp32 kernel.
+//
+// Data movement: X is fixed over the 50 iterations, so ms_split_kernel lays it out ONCE per call as a sequence of
+// 64-key stage images (70 KiB each: h and l planes of X [key][feature] for the first product and of X^T [feature][key]
+// for the second, rows padded by 16 B -> conflict-free ds_read_b128, element order = the MFMA operand slot order so
+// that every operand is one 16-byte read).  A stage image is copied to LDS by LDS-DMA (global_load_lds_dwordx4: linear
+// copy, no staging registers), double buffered, one barrier per 64 keys.
+// One workgroup = 256 query rows (8 waves x 32) x all keys x all iterations; Q lives in registers as MFMA B operands,
+// the O^T accumulator layout is the Q operand layout of the next iteration (as in ms_iterate.hip).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+
+// Stage image for KT keys (KT = 64: 70 KiB, one 8-wave workgroup per CU; KT = 32: 37 KiB, two 4-wave workgroups per CU)
+template <int KT_>
+struct StageLayout {
+    static constexpr int KT = KT_;
+    static constexpr int XROW = 272;                     // bytes per key row of an X plane: 128 halves + 16 pad
+    static constexpr int TROW = 2 * KT + 16;             // bytes per feature row of an X^T plane: KT halves + 16 pad
+    static constexpr int XPLANE = KT * XROW;
+    static constexpr int TPLANE = 128 * TROW;
+    static constexpr int OFF_XH = 0, OFF_XL = XPLANE, OFF_TH = 2 * XPLANE, OFF_TL = 2 * XPLANE + TPLANE;
+    static constexpr int STAGE = 2 * XPLANE + 2 * TPLANE;        // 71680 / 37888 B: whole 1 KiB DMA pieces
+    static_assert(STAGE % 1024 == 0, "stage image must be a whole number of wave-sized DMA pieces");
+};
+constexpr float SCALE_X = 2048.0f;               // 2^11
+constexpr float LOG2_SCALE_P = 14.0f;            // P is produced as 2^14 p
+constexpr float UNSCALE_Q = 1.0f / 2048.0f;
+constexpr float UNSCALE_O = 1.0f / 2048.0f;      // O carries 2^11 (X) * 2^14 (P); the row sum carries 2^14
+
+// position of element m (0..31) of a 32-group in MFMA operand slot order: the accumulator row of register r on lane
+// half hi is (r & 3) + 8 (r >> 2) + 4 hi; slot (j = r >> 3, hi, i = r & 7) sits at j * 16 + hi * 8 + i
+__host__ __device__ constexpr int slot_pos(int m) {
+    return (m >> 4) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3);
+}
+
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// X [B, N, 128] fp32 -> stage images [B, nst, STAGE] + per-cloud fallback flag. One workgroup per (stage, cloud).
+template <int KT_>
+__global__ __launch_bounds__(256) void ms_split_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                       uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
+                                                       int nst) {
+    using L = StageLayout<KT_>;
+    constexpr int KT = L::KT, XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t img[];    // STAGE bytes
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    for (int i = tid; i < STAGE / 16; i += 256) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    float n2max = 0.f;
+    for (int e = tid; e < KT * 32; e += 256) {             // one float4 of one key row per step
+        const int kk = e >> 5, d0 = (e & 31) * 4;
+        const int key = stage * KT + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * 128 + d0);
+        float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);      // 32 lanes = one key row
+        n2max = fmaxf(n2max, n2);
+        const int sub = kk >> 5, km = kk & 31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u, c = d >> 5, m = d & 31;
+            const float s = v[u] * SCALE_X;
+            const h16 h = (h16)s;
+            const h16 l = (h16)(s - (float)h);
+            const int xo = kk * XROW + 2 * (c * 32 + slot_pos(m));
+            const int to = d * TROW + 2 * (sub * 32 + slot_pos(km));
+            *(h16*)(img + OFF_XH + xo) = h;
+            *(h16*)(img + OFF_XL + xo) = l;
+            *(h16*)(img + OFF_TH + to) = h;
+            *(h16*)(img + OFF_TL + to) = l;
+        }
+    }
+    const float b = bw[cloud];
+    if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);           // also catches NaN rows
+    __syncthreads();
+    uint4* dst = (uint4*)(blob + ((size_t)cloud * nst + stage) * STAGE);
+    for (int i = tid; i < STAGE / 16; i += 256) dst[i] = ((const uint4*)img)[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int KT_, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16_kernel(const float* __restrict__ X,
+                                                                     const uint8_t* __restrict__ blob,
+                                                                     float* __restrict__ newX,
+                                                                     const float* __restrict__ bw,
+                                                                     const int* __restrict__ flags, int N, int iters) {
+    using L = StageLayout<KT_>;
+    constexpr int KT = L::KT, XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NSUB = KT / 32;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [2][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);          // whole clouds per XCD (common.h)
+    if (flags[cloud]) return;                            // rows not unit: the exact fp32 kernel takes this cloud
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + KT - 1) / KT;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * (32 * NW) + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    // exponent in the log2 domain with the 2^14 weight scale folded in:  log2(2^14 p) = K1 * S + K0,
+    // S = 2^22 q.x ;  -dist / b^2 / 2 = (q.x - 1) / b^2.  Rounding K1 / K0 is a relative perturbation of b by < 1e-7 /
+    // a common factor of all weights of a cloud (cancels in O / sum).
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;          // guard_exp's -75 clamp
+
+    // Q operand planes: k-step ks = 2 c + j holds features 32 c + row(8 j + i, hi), i = 0..7
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v /* 8 values, already * 2^11 */) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // LDS-DMA of one stage image: STAGE / 1024 pieces of 1 KiB, piece p -> wave p % NW
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE + lane * 16;
+        uint8_t* dst = lds + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < (STAGE / 1024 + NW - 1) / NW; ++t) {
+            const int piece = wave + NW * t;
+            if (piece < STAGE / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0,
+                                                 0);
+        }
+    };
+
+    stage_dma(0, 0);
+    __syncthreads();
+    int cur = 0;
+
+    const int xoff = li * XROW + hi * 16;               // + ks * 32            (first product A operand)
+    const int toff = li * TROW + hi * 16;               // + c * 32 * TROW + sub * 64 + j * 32   (second product)
+
+    for (int it = 0; it < iters; ++it) {
+        f32x16 o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+        float rsum = 0.f;
+        const bool fwd = (it & 1) == 0;                  // ping-pong key sweep (L2 re-use after the turn-around)
+        for (int jst = 0; jst < nst; ++jst) {
+            const int st = fwd ? jst : nst - 1 - jst;
+            const bool last = (it == iters - 1) && (jst == nst - 1);
+            if (!last) stage_dma(jst + 1 == nst ? st : (fwd ? st + 1 : st - 1), cur ^ 1);
+            const uint8_t* base = lds + cur * STAGE;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = st * KT + sub * 32;
+                if (key0 < N) {                                   // block-uniform
+                    const uint8_t* xa = base + sub * 32 * XROW + xoff;
+                    f32x16 s;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const h16x8 xh = *(const h16x8*)(xa + OFF_XH + ks * 32);
+                        const h16x8 xl = *(const h16x8*)(xa + OFF_XL + ks * 32);
+                        s = mfma16(xl, qh[ks], s);
+                        s = mfma16(xh, ql[ks], s);
+                        s = mfma16(xh, qh[ks], s);
+                    }
+                    // weights 2^14 exp(clamp(-(2 - 2 q.x) / b^2 / 2))  (mean_shift.py:60-63, guard.py:7-9)
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                    if (key0 + 32 > N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                    }
+                    h16x8 ph[2], pl[2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        rsum += p[r];
+                        const h16 h = (h16)p[r];
+                        ph[r >> 3][r & 7] = h;
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    }
+                    const uint8_t* ta = base + toff + sub * 64;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const h16x8 th = *(const h16x8*)(ta + OFF_TH + c * 32 * TROW + j * 32);
+                            const h16x8 tl = *(const h16x8*)(ta + OFF_TL + c * 32 * TROW + j * 32);
+                            o[c] = mfma16(tl, ph[j], o[c]);
+                            o[c] = mfma16(th, pl[j], o[c]);
+                            o[c] = mfma16(th, ph[j], o[c]);
+                        }
+                }
+            }
+            __syncthreads();             // next stage landed (vmcnt drained before the barrier), this one is free
+            cur ^= 1;
+        }
+
+        // ---- row update (mean_shift.py:70-77): q <- normalize(q + (O / sum - q))
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
+// cfg 0: 64-key stages, one 8-wave workgroup (256 query rows) per CU; cfg 1: 32-key stages, two 4-wave workgroups per CU
+int g_ms_f16_cfg = 0;
+
+static size_t f16_blob_bytes(int B, int N, int cfg) {
+    const size_t kt = cfg == 0 ? 64 : 32;
+    const size_t stage = cfg == 0 ? StageLayout<64>::STAGE : StageLayout<32>::STAGE;
+    return (size_t)B * ((N + kt - 1) / kt) * stage;
+}
+
+size_t ms_f16_workspace_bytes(int B, int N) {
+    return f16_blob_bytes(B, N, g_ms_f16_cfg) + (((size_t)B * sizeof(int) + 255) / 256) * 256;
+}
+
+template <int KT_, int NW>
+static int f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                      hipStream_t stream) {
+    using L = StageLayout<KT_>;
+    const int nst = (N + KT_ - 1) / KT_;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<KT_>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16_kernel<KT_, NW>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<KT_><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16_kernel<KT_, NW><<<dim3((N + 32 * NW - 1) / (32 * NW), B), 64 * NW, 2 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// flags live behind the stage images; *flags_out = the per-cloud "rows not unit" flags the exact fp32 kernel reads
+int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                  int** flags_out, hipStream_t stream) {
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, g_ms_f16_cfg));
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    return g_ms_f16_cfg == 0 ? f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream)
+                             : f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
+}
+
+extern "C" int sed_ms_set_f16_config(int cfg) {
+    if (cfg < 0 || cfg > 1) return SED_EINVAL;
+    g_ms_f16_cfg = cfg;
+    return SED_OK;
+}

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sed_ms_iterate_sparse_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P]),
     "sed_ms_iterate_bounds_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, P, P, P, c_int, c_float, P]),
     "sed_ms_set_variant": (c_int, [c_int]),
+    "sed_ms_set_f16_config": (c_int, [c_int]),
     "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_nms_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sed_edgeconv_partials_bytes": (c_size_t, [c_int, c_int, c_int]),

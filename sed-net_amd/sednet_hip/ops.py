@@ -228,7 +228,7 @@ def ms_iterate(X, bw, iters):
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    nws = lib.sed_ms_iterate_workspace_bytes(B, N, D)      # > 0: few clouds, the key-chunked schedule fills the CUs
+    nws = lib.sed_ms_iterate_workspace_bytes(B, N, D)      # split-fp16 stage images (d = 128) / key-chunked partials
     ws = torch.empty((nws,), dtype=torch.uint8, device=X.device) if nws else None
     check(lib.sed_ms_iterate_ws_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), ptr(ws) if nws else None, nws,
                                     stream()), "ms_iterate")
@@ -239,9 +239,11 @@ def ms_iterate(X, bw, iters):
 
 
 def ms_set_variant(variant):
-    """Force the d = 128 mean-shift schedule: "auto" (by grid size), "batched", "splitk" or "chunked"
-    (tests / measurements)."""
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3}[variant]), "ms_set_variant")
+    """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
+    "f16" (split-fp16 MFMA emulation; "f16b" = its 4-wave / 32-key-stage configuration) (tests / measurements)."""
+    check(lib.sed_ms_set_f16_config(1 if variant == "f16b" else 0), "ms_set_f16_config")
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16b": 4}[variant]),
+          "ms_set_variant")
 
 
 def ms_nms(centres, X, bw):

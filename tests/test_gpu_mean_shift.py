@@ -44,7 +44,7 @@ def variant(request):
     ops.ms_set_variant("auto")
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked"], indirect=True)
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16b"], indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
@@ -88,7 +88,8 @@ def test_mean_shift_end_to_end(T, golden):
 
 
 def test_iteration_variants_agree_at_full_size(T):
-    """Batched and split-key kernels differ only in summation order: 10 000 points, ragged last tile, 3 clouds."""
+    """The fp32 schedules differ only in summation order, the split-fp16 kernel in how the two products are evaluated
+    (3 fp16 MFMAs on exact (h, l) splits, fp32 accumulation): 10 000 points, ragged last tile, 3 clouds."""
     from sednet_hip import ops, synth
     Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + c, sigma=0.02, seed=40 + c)[0]
                    for c in range(3)])
@@ -96,7 +97,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16b"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -106,10 +107,12 @@ def test_iteration_variants_agree_at_full_size(T):
     # 50 iterations amplify the rounding differences of points still moving (the golden test allows 1e-5 too)
     np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
-    assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all()
+    np.testing.assert_allclose(res["f16"], res["splitk"], atol=2e-5)
+    np.testing.assert_allclose(res["f16"], res["f16b"], atol=2e-6)   # same arithmetic, 32- vs 64-key sweep order
+    assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16"]).all()
     one = {}
     try:
-        for v in ("batched", "splitk", "chunked"):
+        for v in ("batched", "splitk", "chunked", "f16"):
             ops.ms_set_variant(v)
             one[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()
     finally:
@@ -123,8 +126,34 @@ def test_iteration_variants_agree_at_full_size(T):
     ref = p @ x64 / p.sum(1, keepdims=True)
     ref /= np.linalg.norm(ref, axis=1, keepdims=True)
     np.testing.assert_allclose(one["splitk"][0][rows], ref, atol=3e-6)
+    np.testing.assert_allclose(one["f16"][0][rows], ref, atol=3e-6)
     np.testing.assert_allclose(one["chunked"][0][rows], ref, atol=5e-6)
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
+
+
+def test_split_fp16_falls_back_for_non_unit_rows(T):
+    """The split-fp16 kernel needs rows of norm <= 1 (its weights are stored as fp16 with a 2^14 scale). A cloud that
+    violates it is flagged on the device by the split kernel and done by the exact fp32 kernel in the same call; the
+    other clouds of the batch are unaffected."""
+    from sednet_hip import ops, synth
+    Xs = np.stack([synth.clustered_embedding(N=3000, d=128, n_clusters=6 + c, sigma=0.02, seed=90 + c)[0]
+                   for c in range(3)])
+    Xs[1] *= np.float32(1.02)                                   # |x|^2 - 1 = 0.04 >> b^2
+    X = dev(T, Xs)
+    bw = T.full((3,), 0.15, device="cuda")
+    try:
+        ops.ms_set_variant("batched")
+        exact = ops.ms_iterate(X, bw, 7).cpu().numpy()
+        ops.ms_set_variant("f16")
+        got = ops.ms_iterate(X, bw, 7).cpu().numpy()
+        clean = ops.ms_iterate(X[[0, 2]].contiguous(), bw[[0, 2]].contiguous(), 7).cpu().numpy()
+    finally:
+        ops.ms_set_variant("auto")
+    np.testing.assert_array_equal(got[1], exact[1])             # the flagged cloud took the fp32 kernel
+    np.testing.assert_array_equal(got[0], clean[0])             # the others the split-fp16 kernel
+    np.testing.assert_array_equal(got[2], clean[1])
+    np.testing.assert_allclose(got[0], exact[0], atol=5e-6)
+    assert not np.array_equal(got[0], exact[0])
 
 
 def test_chunked_schedule_other_widths(T):

@@ -107,8 +107,9 @@ int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, c
  * (default: split-fp16 whenever the workspace is given), 1 = batched, 2 = split-key, 3 = key-chunked, 4 = split-fp16
  * (tests, measurements). */
 int sed_ms_set_variant(int variant);
-/* split-fp16 schedule: 0 = 64-key stages, one 8-wave workgroup per CU (default); 1 = 32-key stages, two 4-wave
- * workgroups per CU (measurements). Changes sed_ms_iterate_workspace_bytes. */
+/* split-fp16 schedule: 0 = pipelined kernel (32-key stages, three LDS buffers, operand ring, wave groups half a block out
+ * of phase; default); 1 = the same with the groups in phase; 2 / 3 = first version, 64-key stages + one 8-wave workgroup
+ * per CU / 32-key stages + two 4-wave workgroups per CU (measurements). Changes sed_ms_iterate_workspace_bytes. */
 int sed_ms_set_f16_config(int cfg);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),

@@ -96,6 +96,37 @@ def fit_cylinder(points, normals, weights):
     return a.astype(F32), center, radius
 
 
+def fit_cylinder_exact(points, normals, weights):
+    """The same estimator as fit_cylinder with the per-point terms in fp32 (the reference's operation order) and every
+    reduction / the 3 x 3 solve in fp64: the rounding-noise-free limit of primitive_forward.py:788-810 -> :750-773 ->
+    fitting_utils.py:36-85. The reference itself evaluates the rank-deficient projected-circle system through its
+    fp32 ridge branch (lambda = 1e-5 .. 1e-4, cond ~ 1e6): its centre scatters around this limit by O(1e-2) along the
+    axis and O(1e-3) across it (tests/golden/f_cyl.npz holds the distribution)."""
+    points = np.asarray(points, F32)
+    normals = np.asarray(normals, F32)
+    w = np.asarray(weights, F32).reshape(-1, 1)
+    a = _smallest_right_singular_vector((w * normals).astype(np.float64)).astype(F32).reshape(3, 1)
+    a = a / (np.linalg.norm(a) + EPS)
+    prj = (points - ((points @ a).T * a).T).astype(F32)
+    sum_w = np.float64(np.sum(w, dtype=np.float64)) + np.float64(EPS)
+    mean = (np.sum((prj * w).astype(np.float64), 0) / sum_w).astype(F32)
+    A = (w * (F32(2) * (-prj + mean))).astype(F32)
+    dot_points = (w * np.sum(prj * prj, 1, keepdims=True, dtype=F32)).astype(F32)
+    normalization = F32(np.sum(dot_points, dtype=np.float64) / sum_w)
+    Y = (w * (dot_points - normalization)).astype(F32)
+    A64, Y64 = A.astype(np.float64), Y.astype(np.float64)
+    if _rank(A) == 3:
+        x = np.linalg.lstsq(A64, Y64, rcond=None)[0]
+    else:
+        AtA = A64.T @ A64
+        lamb = best_lambda(AtA.astype(F32))
+        x = np.linalg.solve(AtA + lamb * np.eye(3), A64.T @ Y64)
+    center = (-x).reshape(1, 3)
+    r2 = np.sum(w[:, 0].astype(np.float64) * np.sum((prj.astype(np.float64) - center) ** 2, 1)) / sum_w
+    r2 = max(r2, 1e-3)
+    return a.astype(F32), center.astype(F32), F32(np.sqrt(max(r2, 1e-5)))
+
+
 def fit_cone(points, normals, weights):
     """primitive_forward.py:812-847 -> (apex [3,1], axis [1,3], theta)."""
     points = np.asarray(points, F32)
@@ -145,7 +176,9 @@ def fit_segments_eval(points, normals, labels, seg_types, min_points=20):
             apex, axis, theta = fit_cone(p, n, w)
             out[s] = ["cone", apex.reshape(1, 3), axis.reshape(3, 1), theta]
         elif t == CYLINDER:
-            a, c, r = fit_cylinder(p, n, w)
+            # the noise-free limit of the reference's estimator (what the HIP kernel computes); the reference's own fp32
+            # ridge solve scatters around it, see fit_cylinder_exact and tests/golden/f_cyl.npz
+            a, c, r = fit_cylinder_exact(p, n, w)
             out[s] = ["cylinder", a, c, r]
         else:
             c, r = fit_sphere(p, w)

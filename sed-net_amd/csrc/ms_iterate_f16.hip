@@ -289,15 +289,257 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16_kernel(co
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Pipelined schedule (the default): 32-key stage images, THREE LDS buffers, one 8-wave workgroup per CU.
+//   * the A operands of both products travel through a 4-slot register ring, loaded three MFMA steps (9 MFMAs) ahead
+//     of their use -- across the phase boundary and across blocks -- so no ds_read latency sits in front of an MFMA
+//     (the first version waited for every operand pair right after issuing it: ~1 LDS latency per 3 MFMAs);
+//   * waves 0-3 and 4-7 (a SIMD hosts wave w and w + 4) run half a block out of phase: per block the first group does
+//     [S, weights | barrier | O-product], the second [barrier | S, weights, O-product], so that one wave's exponentials
+//     and fp16 splits overlap the other's MFMAs instead of both stalling the matrix pipe at the same time;
+//   * block n lives in buffer n % 3. The barrier of block n (B_n) is passed once every wave has drained the DMA of
+//     block n + 1 (issued after B_{n-1}) and finished every read of block n - 1 (both groups are past its O-product), so
+//     after B_n the DMA of block n + 2 may overwrite buffer (n - 1) % 3 and block n + 1 may be read -- which is what the
+//     ring prefetch at the end of block n's O-product does.
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    const bool late = STAGGER && wave >= 4;              // second group: barrier first
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + 31) >> 5;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 4 w .. 4 w + 3 through the instruction's immediate
+    // offset (it applies to the global and to the LDS address alike), waves 0-4 also piece 32 + w; scalar bases + one
+    // per-lane 32-bit offset, no per-piece address registers
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = iters * nst;
+    int st_cur = 0, st_dma = 0;
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 2
+    __syncthreads();
+
+    // operand ring: step t of a block uses slot t & 3; steps 0-7 = first product (k-step t), 8-15 = second product
+    // (feature tile (t - 8) >> 1, key half (t - 8) & 1); step t's loads are issued after step t - 3's MFMAs
+    h16x8 fa[4], fb[4];
+    const int xoff = li * XROW + hi * 16;
+    const int toff = li * TROW + hi * 16;
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+    if (total > 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ring_load(t, lds);
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % 3
+    h16x8 ph[2], pl[2];
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const int key0 = st_cur * 32;
+
+        auto first_product_and_weights = [&]() {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                s = mfma16(fb[t & 3], qh[t], s);
+                s = mfma16(fa[t & 3], ql[t], s);
+                s = mfma16(fa[t & 3], qh[t], s);
+                ring_load(t + 3, base);
+                __builtin_amdgcn_sched_barrier(0);       // keep the loads three steps ahead of their use
+            }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+            if (key0 + 32 > N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                rsum += p[r];
+                const h16 h = (h16)p[r];
+                ph[r >> 3][r & 7] = h;
+                pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+            }
+        };
+
+        if (!late) first_product_and_weights();
+        __syncthreads();                                  // B_n
+        if (n + 2 < total) stage_dma(st_dma, buf == 0 ? 2 : buf - 1);       // block n + 2 -> buffer (n + 2) % 3
+        advance(st_dma, fwd_dma);
+        if (late) first_product_and_weights();
+
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            o[c] = mfma16(fb[t & 3], ph[j], o[c]);
+            o[c] = mfma16(fa[t & 3], pl[j], o[c]);
+            o[c] = mfma16(fa[t & 3], ph[j], o[c]);
+            if (t + 3 < 16) ring_load(t + 3, base);
+            else if (n + 1 < total) ring_load(t + 3 - 16, nbase);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const bool sweep_end = fwd_cur ? st_cur == nst - 1 : st_cur == 0;
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (sweep_end) {
+            const float rs = rsum + xor32(rsum);
+            const float Dinv = UNSCALE_O / rs;
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float q =
+                        ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                    const float m = o[c][r] * Dinv - q;
+                    const float nq = q + m;
+                    o[c][r] = nq;
+                    n2 += nq * nq;
+                }
+            n2 += xor32(n2);
+            const float nrm = sqrtf(n2);
+            if (n == total - 1) {
+                if (qrow < N) {
+                    float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                       o[c][4 * g + 3] / nrm};
+                            *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                        split_q(2 * c + j, v);
+                    }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+                rsum = 0.f;
+            }
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
-// cfg 0: 64-key stages, one 8-wave workgroup (256 query rows) per CU; cfg 1: 32-key stages, two 4-wave workgroups per CU
+// cfg 0: pipelined 8-wave kernel, wave groups half a block out of phase (default); 1: the same, groups in phase;
+// 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave workgroups per CU
 int g_ms_f16_cfg = 0;
 
 static size_t f16_blob_bytes(int B, int N, int cfg) {
-    const size_t kt = cfg == 0 ? 64 : 32;
-    const size_t stage = cfg == 0 ? StageLayout<64>::STAGE : StageLayout<32>::STAGE;
+    const size_t kt = cfg == 2 ? 64 : 32;
+    const size_t stage = cfg == 2 ? StageLayout<64>::STAGE : StageLayout<32>::STAGE;
     return (size_t)B * ((N + kt - 1) / kt) * stage;
 }
 
@@ -327,6 +569,28 @@ static int f16_launch(int B, int N, int iters, const float* bw, const float* X, 
     return SED_OK;
 }
 
+template <bool STAGGER>
+static int f16p_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<STAGGER>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16p_kernel<STAGGER><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw,
+                                                                                                  flags, N, iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
 // flags live behind the stage images; *flags_out = the per-cloud "rows not unit" flags the exact fp32 kernel reads
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                   int** flags_out, hipStream_t stream) {
@@ -335,12 +599,14 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    return g_ms_f16_cfg == 0 ? f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream)
-                             : f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
+    return g_ms_f16_cfg == 0 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
+                             : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 1) return SED_EINVAL;
+    if (cfg < 0 || cfg > 3) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

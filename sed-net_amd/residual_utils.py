@@ -54,7 +54,9 @@ class Evaluation:
                     lamb=lamb)
                 ids = cluster_ids.cpu().numpy()
                 weights = to_one_hot(ids, np.unique(ids).shape[0]).T
-            s_iou, p_iou, _ = SIOU_matched_segments(labels[b], cluster_ids.cpu().numpy(), prim_pred[b], primitives[b])
+            ids_np = cluster_ids.cpu().numpy()
+            hard = to_one_hot(ids_np, np.unique(ids_np).shape[0]) if eval else weights.T         # :145-150 (weights.T)
+            s_iou, p_iou = SIOU_matched_segments(labels[b], ids_np, prim_pred[b], primitives[b], hard)[:2]
             loss = loss + [s_iou, p_iou]
         return loss, [parameters, cluster_ids.cpu().numpy(), weights]
 

@@ -240,9 +240,10 @@ def ms_iterate(X, bw, iters):
 
 def ms_set_variant(variant):
     """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
-    "f16" (split-fp16 MFMA emulation; "f16b" = its 4-wave / 32-key-stage configuration) (tests / measurements)."""
-    check(lib.sed_ms_set_f16_config(1 if variant == "f16b" else 0), "ms_set_f16_config")
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16b": 4}[variant]),
+    "f16" (split-fp16 MFMA emulation, pipelined kernel; "f16i" = its wave groups in phase, "f16v1" / "f16b" = the first,
+    unpipelined version with 64-key / 32-key stages) (tests / measurements)."""
+    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3}.get(variant, 0)), "ms_set_f16_config")
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3}.get(variant, 4)),
           "ms_set_variant")
 
 

@@ -35,15 +35,20 @@ class _StageTimer:
 class SegmentationPipeline:
     stage_times = None            # set to a list to collect per-stage event pairs (bench.py)
 
-    def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True):
+    def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True, dist=None):
+        """dist: an initialised torch.distributed (world > 1) -> the guard loop's retry passes are balanced over the
+        ranks (every rank must then call the pipeline the same number of times)."""
         from src.mean_shift import MeanShift
         self.model_type, self.model_inst = model_type, model_inst
         self.quantile, self.iterations, self.S, self.fit = quantile, iterations, max_segments, fit
-        self.ms = MeanShift()
+        self.ms, self.dist = MeanShift(), dist
 
     @torch.no_grad()
-    def __call__(self, x6):
-        """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors."""
+    def __call__(self, x6, embedding=None, types=None):
+        """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors.
+        embedding [B,N,d] / types [B,N] i32: replace the instance model's embedding / the type model's argmax AFTER both
+        forwards have run (bench.py's realistic leg and the full-size tests plant cluster structure that closed-form
+        weights cannot produce; with real checkpoints leave them None)."""
         ev = _StageTimer(self.stage_times)
         x6 = x6.float().contiguous()
         # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
@@ -51,12 +56,15 @@ class SegmentationPipeline:
         idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
         ev.mark("input_graph")
         _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
-        types = ops.row_argmax(log_prob, log_prob.shape[2])
+        t_model = ops.row_argmax(log_prob, log_prob.shape[2])
         ev.mark("type_model")
         emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
         X = ops.row_normalize(emb, emb.shape[2])
+        if embedding is not None:
+            X = ops.row_normalize(embedding.float().contiguous(), embedding.shape[2])
+        types = t_model if types is None else types.int().contiguous()
         ev.mark("instance_model")
-        labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations)
+        labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations, dist=self.dist)
         ev.mark("mean_shift")
         out = {"labels": labels, "types": types, "bw": bw, "n_labels": n_labels, "passes": passes, "edges": edges}
         if self.fit:

@@ -185,3 +185,25 @@ def clustered_embedding(N=10000, d=128, n_clusters=12, sigma=0.01, seed=0):
     X = C[assign] + rng.normal(scale=sigma, size=(N, d))
     X /= np.linalg.norm(X, axis=1, keepdims=True)
     return X.astype(F32), assign.astype(np.int64)
+
+
+def realistic_embedding(N=10000, d=128, n_clusters=14, sigma=0.02, bridge=0.04, seed=0):
+    """Embedding of a "trained-network-like" cloud: unit rows around `n_clusters` centres of UNEQUAL size, two of the
+    centres close to each other (0.35 rad), and a fraction `bridge` of the points spread along the arc between
+    neighbouring centres (the points whose cluster is decided by the last bits of the mean-shift arithmetic).
+    -> (X [N,d] fp32, nominal assignment [N])."""
+    rng = np.random.default_rng(seed)
+    C = rng.normal(size=(n_clusters, d))
+    C /= np.linalg.norm(C, axis=1, keepdims=True)
+    t = rng.normal(size=d); t -= t.dot(C[0]) * C[0]; t /= np.linalg.norm(t)
+    C[1] = np.cos(0.35) * C[0] + np.sin(0.35) * t                     # a close pair
+    sizes = rng.dirichlet(np.full(n_clusters, 2.0))
+    assign = rng.choice(n_clusters, size=N, p=sizes)
+    X = C[assign] + rng.normal(scale=sigma, size=(N, d))
+    nb = int(bridge * N)
+    rows = rng.choice(N, nb, replace=False)
+    other = (assign[rows] + 1 + rng.integers(0, n_clusters - 1, size=nb)) % n_clusters
+    lam = rng.uniform(0.0, 0.5, size=(nb, 1))
+    X[rows] = (1 - lam) * C[assign[rows]] + lam * C[other] + rng.normal(scale=sigma, size=(nb, d))
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    return X.astype(F32), assign.astype(np.int64)

@@ -84,34 +84,72 @@ class MeanShift:
         labels, ids, n_c, n_l = ops.ms_nms(new_Xp, Xp, bw)
         return new_Xp[:, :, :d], bw, labels, ids, n_c, n_l
 
-    def guard_mean_shift_batch(self, X, quantile, iterations, num_samples=10000, factor=1.2, max_clusters=49):
+    def guard_mean_shift_batch(self, X, quantile, iterations, num_samples=10000, factor=1.2, max_clusters=49,
+                               dist=None):
         """Batched form of the script-level guard loop (generate_predictions_aug.py:25-35): every cloud
-        whose label count exceeds `max_clusters` is re-run with its own quantile *= factor.
+        whose label count exceeds `max_clusters` is re-run with its own quantile *= factor -- as further passes over
+        ONLY those clouds. With `dist` (an initialised torch.distributed, world > 1) the retry passes are collective and
+        spread over all ranks (sednet_hip.shard.balanced_guard_retries); every rank must then call this method.
         -> (labels [B,N] i32, bw [B], n_labels [B] i32 (host), passes [B] (host))."""
         B = X.shape[0]
         q = np.full(B, float(quantile))
-        todo = np.arange(B)
         labels = torch.empty(X.shape[:2], dtype=torch.int32, device=X.device)
         bw = torch.empty((B,), dtype=torch.float32, device=X.device)
         n_labels = np.zeros(B, np.int64)
         passes = np.zeros(B, np.int64)
-        while todo.size:
-            groups = {}
-            for b in todo:                      # clouds sharing a quantile share K -> one launch
-                groups.setdefault(q[b], []).append(b)
+
+        def run(Xs, qs):
+            """one pass over the clouds Xs with per-cloud quantiles qs: clouds sharing a quantile share K -> one launch"""
+            lab = torch.empty(Xs.shape[:2], dtype=torch.int32, device=Xs.device)
+            b = torch.empty((Xs.shape[0],), dtype=torch.float32, device=Xs.device)
+            nl = torch.empty((Xs.shape[0],), dtype=torch.int64, device=Xs.device)
+            for qq in np.unique(qs):
+                members = np.nonzero(qs == qq)[0]
+                whole = members.size == Xs.shape[0]
+                sel = None if whole else torch.as_tensor(members, device=Xs.device)
+                _, bw_g, lab_g, _, _, nl_g = self.mean_shift_batch(Xs if whole else Xs[sel], num_samples, float(qq),
+                                                                   iterations)
+                if whole:
+                    lab, b, nl = lab_g, bw_g, nl_g.long()
+                else:
+                    lab[sel], b[sel], nl[sel] = lab_g, bw_g, nl_g.long()
+            return lab, b, nl
+
+        distributed = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        todo = np.arange(B)
+        first = True
+        while True:
+            if first or not distributed:
+                if todo.size == 0:
+                    break
+                whole = todo.size == B
+                sel = None if whole else torch.as_tensor(todo, device=X.device)
+                lab_t, bw_t, nl_t = run(X if whole else X[sel], q[todo])
+            else:
+                from sednet_hip.shard import balanced_guard_retries
+                sel = torch.as_tensor(todo, device=X.device)
+                lab_t, bw_t, nl_t = balanced_guard_retries(X[sel], q[todo], run, dist)
+                whole = False
+            if whole:
+                labels, bw = lab_t, bw_t
+            elif todo.size:
+                labels[sel], bw[sel] = lab_t, bw_t
+            nl = nl_t.cpu().numpy()              # the one D->H sync per pass (reference: :31)
             nxt = []
-            for qq, members in groups.items():
-                sel = torch.as_tensor(members, device=X.device)
-                _, bw_g, lab_g, _, _, nl_g = self.mean_shift_batch(X[sel], num_samples, qq, iterations)
-                labels[sel], bw[sel] = lab_g, bw_g
-                nl = nl_g.cpu().numpy()          # the one D->H sync per pass (reference: :31)
-                for b, n in zip(members, nl):
-                    n_labels[b] = n
-                    passes[b] += 1
-                    if n > max_clusters:
-                        q[b] *= factor
-                        nxt.append(b)
+            for b_, n in zip(todo, nl):
+                n_labels[b_] = n
+                passes[b_] += 1
+                if n > max_clusters:
+                    q[b_] *= factor
+                    nxt.append(b_)
             todo = np.array(nxt, dtype=np.int64)
+            first = False
+            if distributed:
+                more = torch.tensor([todo.size], dtype=torch.int64,
+                                    device=X.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(more)
+                if int(more.item()) == 0:
+                    break
         return labels, bw, n_labels, passes
 
     # ------------------------------------------------------------------ helpers

@@ -66,20 +66,31 @@ def match(target, pred_labels):
 
 
 def SIOU_matched_segments(target, pred_labels, primitives_pred, primitives, weights=None):
-    """segment_utils.py:140-185 restated for hard labels: (segment IoU, primitive-type IoU over matched segments,
-    matching). Type ids are folded like the reference ({0,6,7} -> 9, 8 -> 2)."""
+    """segment_utils.py:140-185 + mean_IOU_primitive_segment :359-421 -> (segment IoU, primitive-type IoU over matched
+    segments, matching, [gt, pred] type pairs, recall). Type ids are folded like the reference ({0,6,7} -> 9, 8 -> 2);
+    ground-truth segments with fewer than 100 points are skipped (:392); the ground-truth type of a segment is its
+    first point's (:406), the predicted type of a predicted segment argmax_L sum_n onehot(pred)[n,L] weights[n,k]
+    (:509-517; weights [N,K], default = one-hot of pred_labels)."""
     fold = lambda a: np.where(np.isin(a, (0, 6, 7)), 9, np.where(a == 8, 2, a))
+    target, pred_labels = np.asarray(target), np.asarray(pred_labels)
     primitives, primitives_pred = fold(np.asarray(primitives)), fold(np.asarray(primitives_pred))
     rids, cids, _, _ = match(target, pred_labels)
-    s_iou = matching_iou([[rids, cids]], np.asarray(pred_labels)[None], np.asarray(target)[None])
-    hits, total = 0, 0
+    if weights is None:
+        weights = to_one_hot(pred_labels, int(pred_labels.max()) + 1)
+    weights = torch.as_tensor(weights).float().cpu()
+    prim_pred = primitive_type_segment_torch(to_one_hot(primitives_pred, 10).cpu(), weights).numpy()
+    iou_b, recall_b, prim_b, pairs = [], [], [], []
     for r, c in zip(rids, cids):
         pi, gi = pred_labels == r, target == c
-        if gi.sum() == 0 or pi.sum() == 0:
+        if gi.sum() == 0 or pi.sum() == 0 or gi.sum() < 100:
             continue
-        total += 1
-        hits += int(np.bincount(primitives_pred[pi]).argmax() == np.bincount(primitives[gi]).argmax())
-    return s_iou, hits / max(total, 1), [[rids, cids]]
+        tp = np.sum(pi & gi)
+        iou_b.append(tp / (np.sum(pi | gi) + 1e-8))
+        recall_b.append(tp / (tp + np.sum(~pi & gi) + 1e-8))
+        gt_t, pred_t = primitives[gi][0], prim_pred[r]
+        prim_b.append(gt_t == pred_t)
+        pairs.append([gt_t, pred_t])
+    return np.mean(iou_b), np.mean(prim_b), [[rids, cids]], pairs, np.mean(recall_b)
 
 
 def primitive_type_segment_torch(pred, weights):

@@ -24,3 +24,18 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+def assert_close_up_to_graph_ties(got, ref, atol, max_frac=5e-4, loose=5e-2, what=""):
+    """Activations behind data-dependent kNN graphs: a k-th / (k+1)-th neighbour whose scores tie to fp32 rounding may
+    be resolved differently than torch.topk did in the reference (its tie order is unspecified), which moves the max over
+    k of a few channels of a few points. All elements must agree to `atol` except a fraction <= max_frac, and those must
+    still agree to `loose`."""
+    import numpy as np
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bad = err > atol
+    assert bad.mean() <= max_frac, f"{what}: {bad.sum()} / {bad.size} elements beyond {atol} (max err {err.max():.3e})"
+    assert err.max() <= loose, f"{what}: max err {err.max():.3e} beyond the near-tie allowance {loose}"
+    return float(bad.mean()), float(err.max())

@@ -24,7 +24,7 @@ REFERENCE_ROOT = "/root/reference"
 _STUB_ROOTS = (
     "turtle", "audioop", "positional_encodings", "open3d", "geomdl", "lapsolver",
     "pykdtree", "h5py", "ipdb", "configobj", "trimesh", "transforms3d", "lap",
-    "tensorboard_logger", "cv2",
+    "tensorboard_logger", "cv2", "pointnet2", "pointnet2_ops", "pyransac3d",
 )
 
 

@@ -27,12 +27,12 @@ def test_bandwidth_matches_golden_and_oracle(T, golden):
     from oracle import mean_shift as oms
     g = golden("f_ms")
     ms = MeanShift()
-    bw = ms.compute_bandwidth(dev(T, g["X"]), 800, 0.05).item()
-    np.testing.assert_allclose(bw, g["bw_q05_ns800"], rtol=2e-5)
-    np.testing.assert_allclose(bw, oms.compute_bandwidth(g["X"], 800, 0.05), rtol=2e-5)
+    bw = ms.compute_bandwidth(dev(T, g["X"]), 2000, 0.05).item()
+    np.testing.assert_allclose(bw, g["bw_q05_ns2000"], rtol=2e-5)
+    np.testing.assert_allclose(bw, oms.compute_bandwidth(g["X"], 2000, 0.05), rtol=2e-5)
     # K from num_samples > N (script-style call), d = 140 -> padded to 160
-    bw140 = ms.compute_bandwidth(dev(T, g["X140"]), 600, 0.05).item()
-    np.testing.assert_allclose(bw140, oms.compute_bandwidth(g["X140"], 600, 0.05), rtol=2e-5)
+    bw140 = ms.compute_bandwidth(dev(T, g["X140"]), 2000, 0.05).item()
+    np.testing.assert_allclose(bw140, oms.compute_bandwidth(g["X140"], 2000, 0.05), rtol=2e-5)
 
 
 @pytest.fixture
@@ -44,12 +44,12 @@ def variant(request):
     ops.ms_set_variant("auto")
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16b"], indirect=True)
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b"], indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
     g = golden("f_ms")
-    bw = max(float(g["bw_q05_ns800"]), 0.003)
+    bw = max(float(g["bw_q05_ns2000"]), 0.003)
     new_X, _ = MeanShift().mean_shift_(dev(T, g["X"]), bw, iterations=iters)
     got = new_X.cpu().numpy()
     ref = g[key]
@@ -60,7 +60,7 @@ def test_iterations_match_golden(T, golden, iters, key, atol, variant):
 def test_nms_labels_match_golden(T, golden):
     from src.mean_shift import MeanShift
     g = golden("f_ms")
-    bw = max(float(g["bw_q05_ns800"]), 0.003)
+    bw = max(float(g["bw_q05_ns2000"]), 0.003)
     cen, ids, labels = MeanShift().nms(dev(T, g["newX_it50"]), dev(T, g["X"]), bw)
     assert ids.shape[0] == 12 and cen.shape == (12, 128)
     assert (np.diff(ids.cpu().numpy()) > 0).all()                # ascending centre ids (torch.unique order)
@@ -72,7 +72,7 @@ def test_mean_shift_end_to_end(T, golden):
     from src.mean_shift import MeanShift
     g = golden("f_ms")
     ms = MeanShift()
-    new_X, center, bw, labels = ms.mean_shift(dev(T, g["X"]), 800, 0.05, 50)
+    new_X, center, bw, labels = ms.mean_shift(dev(T, g["X"]), 2000, 0.05, 50)
     np.testing.assert_allclose(float(bw), g["ms_bw"], rtol=2e-5)
     np.testing.assert_array_equal(canon(labels.cpu().numpy()), canon(g["ms_labels"]))
     assert labels.dtype == T.int64 and center.shape[1] == 128
@@ -82,7 +82,7 @@ def test_mean_shift_end_to_end(T, golden):
     np.testing.assert_allclose(float(bw), g["script_bw"], rtol=2e-5)
     np.testing.assert_array_equal(canon(labels.cpu().numpy()), canon(g["script_labels"]))
     # d = 140
-    _, _, bw, labels = ms.mean_shift(dev(T, g["X140"]), 600, 0.05, 50)
+    _, _, bw, labels = ms.mean_shift(dev(T, g["X140"]), 2000, 0.05, 50)
     np.testing.assert_allclose(float(bw), g["bw140"], rtol=2e-5)
     np.testing.assert_array_equal(canon(labels.cpu().numpy()), canon(g["labels140"]))
 
@@ -97,7 +97,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16b"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -108,7 +108,9 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["f16"], res["splitk"], atol=2e-5)
-    np.testing.assert_allclose(res["f16"], res["f16b"], atol=2e-6)   # same arithmetic, 32- vs 64-key sweep order
+    np.testing.assert_array_equal(res["f16"], res["f16i"])           # same arithmetic and order, different schedule
+    np.testing.assert_array_equal(res["f16"], res["f16b"])
+    np.testing.assert_allclose(res["f16"], res["f16v1"], atol=2e-6)  # 32- vs 64-key stages: order of the backward sweeps
     assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16"]).all()
     one = {}
     try:

@@ -98,3 +98,45 @@ def test_evaluation_caller_contract(T):
     loss_t = ev.fitting_loss(cu(E[None]), cu(p[None]), cu(n[None]), l[None], t[None], cu(logp), quantile=0.01,
                              iterations=20, eval=False)[0]
     assert np.isfinite(float(loss_t[0]))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_evaluation_caller_matches_reference(T, golden, tag):
+    """SURVEY section 8 row f-2, pinned: residual_utils.Evaluation.fitting_loss(eval=True) on the MI355X kernels against
+    the outputs of the reference's own class (tests/golden/f_eval.npz, captured by make_golden.gen_eval from
+    /root/reference/Fitting_patches_and_edges/residual_utils.py): cluster ids after canonicalisation, parameter dict,
+    losses, seg / type IoU; train-mode forward values as well."""
+    import residual_utils as ru
+    from oracle.mean_shift import canonical_labels
+    from test_oracle_golden import _check_eval_losses, _check_eval_params
+    g = golden("f_eval")
+    G = lambda k: g[f"{tag}_{k}"]
+    cu = lambda a: T.from_numpy(np.ascontiguousarray(a)).cuda()
+    ev = ru.Evaluation()
+    seen, sep = {}, ev.separate_losses
+
+    def record(distance, gt_points, lamb=1.0):                    # per-segment residuals before the mean
+        seen["distance"] = {k: float(v[1]) for k, v in distance.items()}
+        return sep(distance, gt_points, lamb=lamb)
+    ev.separate_losses = record
+    lab, typ = G("labels").astype(np.int64), G("types").astype(np.int64)
+    loss, (params, ids, weights) = ev.fitting_loss(cu(G("E")[None]), cu(G("p")[None]), cu(G("n")[None]), lab[None].copy(),
+                                                   typ[None].copy(), cu(G("logp")), quantile=float(G("quantile")),
+                                                   iterations=int(G("iterations")), eval=True)
+    np.testing.assert_array_equal(canonical_labels(ids), canonical_labels(G("cluster_ids")))
+    to_ref = {int(a): int(b) for a, b in zip(ids, G("cluster_ids"))}
+    host = {to_ref[k]: (None if v is None else [v[0]] + [x.detach().cpu().numpy() if T.is_tensor(x) else x for x in v[1:]])
+            for k, v in params.items()}
+    _check_eval_params(G("param_kinds"), G("param_keys"), G("param_values"), host)
+    _check_eval_losses(G("param_kinds"), G("param_keys"), G("param_residual"),
+                       {to_ref[k]: v for k, v in seen["distance"].items()}, loss, G("loss"))
+    w_ref = G("weights")                                          # [K, N] hard membership, rows = reference label ids
+    w = weights.cpu().numpy()
+    assert w.shape == w_ref.shape
+    for k_mine, k_ref in to_ref.items():
+        np.testing.assert_array_equal(w[k_mine], w_ref[k_ref])
+    loss_t = ev.fitting_loss(cu(G("E")[None]), cu(G("p")[None]), cu(G("n")[None]), lab[None].copy(), typ[None].copy(),
+                             cu(G("logp")), quantile=float(G("quantile")), iterations=int(G("iterations")), eval=False)[0]
+    ref_t = G("train_loss")                                       # [Loss, geometric, s_iou, p_iou]
+    np.testing.assert_allclose([float(loss_t[0]), float(loss_t[1])], ref_t[:2], rtol=0.2, atol=5e-4)
+    np.testing.assert_allclose([loss_t[3], loss_t[4]], ref_t[2:], atol=1e-7)

@@ -42,26 +42,27 @@ def test_knn_subsample_and_graph_feature(golden):
 def test_backbone_matches_reference(golden):
     g = golden("f_e2e")
     params = synth.closed_form_state_dict(int(g["salt"]))
+    from conftest import assert_close_up_to_graph_ties as close
     x4, feats = backbone.encoder_forward(params, g["x"], int(g["k"]))
-    np.testing.assert_allclose(feats, g["feats"], rtol=0, atol=2e-4)
-    np.testing.assert_allclose(x4, g["x4"], rtol=0, atol=2e-4)
+    close(feats, g["feats"], 2e-4, what="feats")
+    close(x4, g["x4"], 2e-4, what="x4")
     emb, logp, edges = backbone.sednet_forward(params, g["x"], int(g["k"]))
-    np.testing.assert_allclose(emb, g["embedding"], rtol=0, atol=5e-4)
-    np.testing.assert_allclose(logp, g["log_prob"], rtol=0, atol=5e-4)
-    np.testing.assert_allclose(edges, g["edges"], rtol=0, atol=5e-4)
+    close(emb, g["embedding"], 5e-4, what="embedding")
+    close(logp, g["log_prob"], 5e-4, what="log_prob")
+    close(edges, g["edges"], 5e-4, what="edges")
     assert (np.argmax(logp, 1) == np.argmax(g["log_prob"], 1)).mean() > 0.999
 
 
 # ------------------------------------------------------------------------------------- F-MS
 def test_bandwidth_matches_reference(golden):
     g = golden("f_ms")
-    bw = mean_shift.compute_bandwidth(g["X"], 800, 0.05)
-    np.testing.assert_allclose(bw, g["bw_q05_ns800"], rtol=2e-5)
+    bw = mean_shift.compute_bandwidth(g["X"], 2000, 0.05)
+    np.testing.assert_allclose(bw, g["bw_q05_ns2000"], rtol=2e-5)
 
 
 def test_mean_shift_iterations_match_reference(golden):
     g = golden("f_ms")
-    bw = max(np.float32(g["bw_q05_ns800"]), np.float32(0.003))
+    bw = max(np.float32(g["bw_q05_ns2000"]), np.float32(0.003))
     snaps = {1: None, 5: None, 50: None}
     mean_shift.mean_shift_iterations(g["X"], bw, 50, snaps)
     np.testing.assert_allclose(snaps[1], g["newX_it1"], atol=2e-6)
@@ -71,7 +72,7 @@ def test_mean_shift_iterations_match_reference(golden):
 
 def test_nms_and_labels_match_reference(golden):
     g = golden("f_ms")
-    bw = max(np.float32(g["bw_q05_ns800"]), np.float32(0.003))
+    bw = max(np.float32(g["bw_q05_ns2000"]), np.float32(0.003))
     _, ids, labels = mean_shift.nms(g["newX_it50"], g["X"], bw)
     # which converged row represents a cluster depends on last-ulp noise; labels after
     # canonicalisation are the invariant.
@@ -84,14 +85,14 @@ def test_nms_and_labels_match_reference(golden):
 
 def test_mean_shift_end_to_end_matches_reference(golden):
     g = golden("f_ms")
-    _, center, bw, labels = mean_shift.mean_shift(g["X"], 800, 0.05, 50)
+    _, center, bw, labels = mean_shift.mean_shift(g["X"], 2000, 0.05, 50)
     np.testing.assert_allclose(bw, g["ms_bw"], rtol=2e-5)
     np.testing.assert_array_equal(mean_shift.canonical_labels(labels), mean_shift.canonical_labels(g["ms_labels"]))
     _, _, bw, labels = mean_shift.mean_shift(g["X"], 10000, 0.015, 50)      # script-style num_samples > N
     np.testing.assert_allclose(bw, g["script_bw"], rtol=2e-5)
     np.testing.assert_array_equal(mean_shift.canonical_labels(labels),
                                   mean_shift.canonical_labels(g["script_labels"]))
-    _, _, bw, labels = mean_shift.mean_shift(g["X140"], 600, 0.05, 50)      # d = 140
+    _, _, bw, labels = mean_shift.mean_shift(g["X140"], 2000, 0.05, 50)      # d = 140
     np.testing.assert_allclose(bw, g["bw140"], rtol=2e-5)
     np.testing.assert_array_equal(mean_shift.canonical_labels(labels), mean_shift.canonical_labels(g["labels140"]))
 
@@ -184,3 +185,106 @@ def test_weight_helpers_and_lstsq(golden):
     np.testing.assert_allclose(fit.lstsq(g["ls_A"], g["ls_Y"]), g["ls_x"], rtol=1e-4, atol=1e-6)
     # rank-deficient -> ridge branch with lambda=1e-6..1e-4 in fp32: ill-conditioned by construction
     np.testing.assert_allclose(fit.lstsq(g["ls_A2"], g["ls_Y"]), g["ls_x2"], rtol=5e-3, atol=1e-3)
+
+
+def _check_eval_params(kinds, keys, values, params, tol=1e-4):
+    """parameter dict {pred label id: [kind, ...] or None} against the reference's (kinds, keys, flattened values)."""
+    assert sorted(params.keys()) == [int(k) for k in keys]
+    for kind, k, v in zip(kinds, keys, values):
+        got = params[int(k)]
+        if str(kind) == "none":
+            assert got is None
+            continue
+        assert got[0] == str(kind)
+        flat = np.concatenate([np.asarray(x, np.float64).reshape(-1) for x in got[1:]])
+        if kind == "plane":                               # normal up to sign (SVD), d follows the sign
+            sgn = np.sign(np.dot(flat[:3], v[:3]))
+            np.testing.assert_allclose(sgn * flat[:4], v[:4], atol=tol)
+        elif kind == "sphere":
+            np.testing.assert_allclose(flat[:4], v[:4], atol=tol)
+        elif kind == "cylinder":                          # well-defined invariants (DESIGN section 2): axis, c_perp, r_perp
+            ax = v[:3] / np.linalg.norm(v[:3])
+            assert min(np.abs(flat[:3] - ax).max(), np.abs(flat[:3] + ax).max()) < tol
+            perp = lambda c: c - np.dot(c, ax) * ax
+            rperp = lambda c, r: np.sqrt(r * r - np.dot(c, ax) ** 2)
+            # the reference's fp32 ridge solve scatters by O(1e-2) (f_cyl.npz, test_cylinder_scatter_of_the_reference)
+            np.testing.assert_allclose(perp(flat[3:6]), perp(v[3:6]), atol=1.5e-2)
+            np.testing.assert_allclose(rperp(flat[3:6], flat[6]), rperp(v[3:6], v[6]), atol=1e-3)
+        else:
+            np.testing.assert_allclose(flat[:3], v[:3], atol=5 * tol)
+            np.testing.assert_allclose(flat[3:7], v[3:7], atol=tol)
+
+
+def _check_eval_losses(kinds, keys, ref_res, got_res, loss, ref_loss):
+    """per-segment residuals {reference label id: value} and the loss list against the reference's. Cylinder segments
+    inherit the scatter of the reference's ridge solve (f_cyl.npz): there the build must not be worse; all other
+    segments agree to 2e-3 relative; Loss / geometric are the mean of the per-segment values (separate_losses)."""
+    vals = []
+    for kind, k, r in zip(kinds, keys, ref_res):
+        if str(kind) == "none":
+            continue
+        got = got_res[int(k)]
+        vals.append(got)
+        if str(kind) == "cylinder":
+            assert got <= r + 1e-4, (kind, k, got, r)
+        else:
+            np.testing.assert_allclose(got, r, rtol=2e-3, err_msg=f"{kind} {k}")
+    np.testing.assert_allclose(float(loss[0]), np.mean(vals), rtol=1e-5)
+    np.testing.assert_allclose(float(loss[1]), np.mean(vals), rtol=1e-5)
+    assert loss[2] is None
+    np.testing.assert_allclose([loss[3], loss[4]], ref_loss[2:], atol=1e-7)     # s_iou, p_iou
+    assert float(loss[0]) <= ref_loss[0] + 1e-4
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_evaluation_caller_matches_reference(golden, tag):
+    """F-EVAL: the reference's Evaluation.fitting_loss(eval=True) -- guarded mean-shift, Hungarian
+    match, per-segment type vote, fits, residuals, separate_losses, seg / type IoU -- against the numpy restatement."""
+    from oracle import evaluation as oev
+    from oracle.mean_shift import canonical_labels
+    g = golden("f_eval")
+    G = lambda k: g[f"{tag}_{k}"]
+    loss, params, ids, res = oev.fitting_loss_eval(G("E"), G("p"), G("n"), G("labels").astype(np.int64),
+                                                   G("types").astype(np.int64), G("logp")[0], float(G("quantile")),
+                                                   int(G("iterations")))
+    np.testing.assert_array_equal(canonical_labels(ids), canonical_labels(G("cluster_ids")))
+    # label ids are positions in the sorted list of representative rows (mean_shift.py:171-173), and which converged row
+    # represents a cluster is last-ulp noise: compare the parameter dicts through the id bijection
+    to_ref = {int(a): int(b) for a, b in zip(ids, G("cluster_ids"))}
+    _check_eval_params(G("param_kinds"), G("param_keys"), G("param_values"), {to_ref[k]: v for k, v in params.items()})
+    _check_eval_losses(G("param_kinds"), G("param_keys"), G("param_residual"), {to_ref[k]: v for k, v in res.items()},
+                       loss, G("loss"))                                               # [Loss, geometric, s_iou, p_iou]
+
+
+def cyl_invariants(axis, c, r):
+    ax = np.ravel(axis).astype(np.float64); ax = ax / np.linalg.norm(ax)
+    c = np.ravel(c).astype(np.float64)
+    cpar = float(np.dot(c, ax))
+    return ax, c - cpar * ax, float(np.sqrt(max(float(r) ** 2 - cpar ** 2, 0.0))), cpar
+
+
+def test_cylinder_scatter_of_the_reference(golden):
+    """F-CYL settles SURVEY row a13: fit_cylinder_torch (primitive_forward.py:788-810) sends a rank-2 system through
+    the fp32 ridge branch of lstsq (fitting_utils.py:52-64, cond ~ 1e6). Its centre is rounding noise along the axis
+    (up to 0.19 here, inflating r by c_par^2 / 2r) and O(1e-2) across it; the noise-free limit of the same estimator
+    (oracle.fit.fit_cylinder_exact, what the HIP kernel computes) is never worse in the reference's OWN residual."""
+    from oracle import fit as ofit
+    g = golden("f_cyl")
+    off = g["offsets"]
+    d_perp, d_r, cpar_ref, cpar_ex, gain = [], [], [], [], []
+    for i in range(off.shape[0] - 1):
+        p, n = g["points"][off[i]:off[i + 1]], g["normals"][off[i]:off[i + 1]]
+        w = np.ones((p.shape[0], 1), np.float32) + np.finfo(np.float32).eps
+        a, c, r = ofit.fit_cylinder_exact(p, n, w)
+        ax_r, cp_r, rp_r, cpar_r = cyl_invariants(g["ref_axis"][i], g["ref_center"][i], g["ref_radius"][i])
+        ax_e, cp_e, rp_e, cpar_e = cyl_invariants(a, c, r)
+        assert min(np.abs(ax_r - ax_e).max(), np.abs(ax_r + ax_e).max()) < 1e-4          # the axis is well posed
+        d_perp.append(np.abs(cp_r - cp_e).max()); d_r.append(abs(rp_r - rp_e))
+        cpar_ref.append(abs(cpar_r)); cpar_ex.append(abs(cpar_e))
+        res_e = float(ofit.residual(p, ["cylinder", a, c, r], sqrt=True))
+        assert res_e <= float(g["ref_residual"][i]) + 1e-4
+        gain.append(float(g["ref_residual"][i]) - res_e)
+    assert max(cpar_ex) < 1e-3 and max(cpar_ref) > 0.1          # the reference's axial centre is noise, the limit's is ~0
+    assert max(d_perp) < 2e-2 and max(d_r) < 1e-3               # scatter of the reference around the limit
+    assert np.median(d_perp) > 5e-4                             # ... which is why 1e-4 on (c, r) cannot be asked for
+    assert max(gain) > 0.04

@@ -53,7 +53,7 @@ def iterate(X, b, iters, mode, snaps):
 
 if __name__ == "__main__":
     g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", sys.argv[1] if len(sys.argv) > 1 else "f_ms.npz"))
-    X = g["X"]; b = max(float(g["bw_q05_ns800"]) if "bw_q05_ns800" in g.files else float(g["bw"]), 0.003)
+    X = g["X"]; b = max(float(g["bw_q05_ns2000"]) if "bw_q05_ns2000" in g.files else float(g["bw"]), 0.003)
     ref = {1: g["newX_it1"], 5: g["newX_it5"], 50: g["newX_it50"]}
     res = {m: iterate(X, b, 50, m, ref) for m in ("f64", "f32", "f16x2")}
     for it in (1, 5, 50):

@@ -81,6 +81,9 @@ int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const fl
  * batches at d = 128 (the reference script's one cloud per call) then run the key-chunked variant, which splits the
  * key sweep of every 128-query block over several workgroups per iteration so that all CUs have work. */
 size_t sed_ms_iterate_workspace_bytes(int B, int N, int d);
+/* the schedule sed_ms_iterate_ws_f32 takes for this shape when given that workspace: 1 batched fp32, 2 split-key fp32,
+ * 3 key-chunked fp32, 4 split-fp16 (sed_ms_set_variant); 0 = unsupported shape */
+int sed_ms_iterate_plan(int B, int N, int d);
 int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                           void* workspace, size_t workspace_bytes, sed_stream_t stream);
 /* Opt-in block-sparse schedule (d = 128): identical arithmetic, except that a wave skips a 32 x 32 (keys x queries) block

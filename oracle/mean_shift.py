@@ -34,6 +34,17 @@ def compute_bandwidth(X, num_samples, quantile, perm=None):
     return np.mean(guard_sqrt(kth, 1e-6), dtype=F32)
 
 
+def mean_shift_step(new_X, X, b):
+    """One iteration of mean_shift.py:56-77 (gaussian kernel): new_X [n,d] against the fixed X [N,d]."""
+    dist = (F32(2.0) - F32(2.0) * (new_X @ X.T)).astype(F32)        # :60
+    K = guard_exp(-dist / (b * b) / F32(2))                        # :63
+    D = (F32(1) / np.sum(K, axis=1, keepdims=True, dtype=F32)).astype(F32)   # :70
+    M = ((K @ X).astype(F32) * D - new_X).astype(F32)             # :73
+    new_X = (new_X + M).astype(F32)                                # :74 (delta = 1)
+    nrm = np.sqrt(np.sum(new_X * new_X, axis=1, keepdims=True, dtype=F32)).astype(F32)
+    return (new_X / nrm).astype(F32)                               # :77
+
+
 def mean_shift_iterations(X, b, iterations, snapshots=None):
     """mean_shift.py:45-79 (gaussian kernel). Returns new_X; optional snapshots dict
     {iteration_count: copy} for golden-vector capture."""
@@ -41,13 +52,7 @@ def mean_shift_iterations(X, b, iterations, snapshots=None):
     b = F32(b)
     new_X = X.copy()
     for it in range(iterations):
-        dist = (F32(2.0) - F32(2.0) * (new_X @ X.T)).astype(F32)        # :60
-        K = guard_exp(-dist / (b * b) / F32(2))                        # :63
-        D = (F32(1) / np.sum(K, axis=1, keepdims=True, dtype=F32)).astype(F32)   # :70
-        M = ((K @ X).astype(F32) * D - new_X).astype(F32)             # :73
-        new_X = (new_X + M).astype(F32)                                # :74 (delta = 1)
-        nrm = np.sqrt(np.sum(new_X * new_X, axis=1, keepdims=True, dtype=F32)).astype(F32)
-        new_X = (new_X / nrm).astype(F32)                              # :77
+        new_X = mean_shift_step(new_X, X, b)
         if snapshots is not None and (it + 1) in snapshots:
             snapshots[it + 1] = new_X.copy()
     return new_X

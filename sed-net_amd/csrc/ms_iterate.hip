@@ -827,6 +827,13 @@ extern "C" int sed_ms_set_variant(int variant) {
     return SED_OK;
 }
 
+// which schedule sed_ms_iterate_ws_f32 runs for this shape when given the workspace it asks for:
+// 1 batched fp32, 2 split-key fp32, 3 key-chunked fp32, 4 split-fp16 (0 = unsupported shape)
+extern "C" int sed_ms_iterate_plan(int B, int N, int d) {
+    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
+    return ms_plan(B, N, d, true, true, g_ms_variant);
+}
+
 extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
     if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
     const int plan = ms_plan(B, N, d, true, true, g_ms_variant);

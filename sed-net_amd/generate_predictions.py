@@ -36,18 +36,22 @@ DROP_OUT_NUM = 2000                                  # generate_predictions_aug.
 ITERATIONS, QUANTILE = 50, 0.015                     # :188-189
 
 
-def build_model(k, ckpt, salt, device, log):
+def build_model(k, ckpt, salt, device, log, synthetic_weights=False):
+    """generate_predictions_aug.py:142-198. A missing checkpoint is an error like in the reference (torch.load raises
+    there); closed-form synthetic weights are used only when asked for with --synthetic-weights (tests, benchmarks)."""
     m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
                combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
-    if ckpt and os.path.exists(ckpt):
-        sd = torch.load(ckpt, map_location="cpu")
-        if list(sd.keys())[0].startswith("module."):                      # :192
-            sd = {k_[k_.find(".") + 1:]: v for k_, v in sd.items()}
-        m.load_state_dict(sd)
-        log.info("loaded %s", ckpt)
-    else:
-        log.warning("checkpoint %r not found: using closed-form synthetic weights (salt %d)", ckpt, salt)
+    if synthetic_weights:
+        log.warning("--synthetic-weights: closed-form synthetic weights (salt %d) instead of %r", salt, ckpt)
         m.load_state_dict({n: torch.from_numpy(v) for n, v in synth.closed_form_state_dict(salt).items()})
+        return m.to(device).eval()
+    if not ckpt or not os.path.exists(ckpt):
+        raise FileNotFoundError(f"checkpoint {ckpt!r} not found (pass --synthetic-weights to run without trained weights)")
+    sd = torch.load(ckpt, map_location="cpu")
+    if list(sd.keys())[0].startswith("module."):                      # :192
+        sd = {k_[k_.find(".") + 1:]: v for k_, v in sd.items()}
+    m.load_state_dict(sd)
+    log.info("loaded %s", ckpt)
     return m.to(device).eval()
 
 
@@ -111,7 +115,12 @@ def main(argv=None):
     ap.add_argument("--points", type=int, default=10000)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--out", default="./predictions/results")
-    ap.add_argument("--hpnet", action="store_true")
+    ap.add_argument("--hpnet", action="store_true",
+                    help="HPNet spectral re-weighting of the embedding (on by default in the reference, :58; off here because "
+                         "its lobpcg start is random: with identical argv the instance labels differ from the reference's "
+                         "unless this flag is given)")
+    ap.add_argument("--synthetic-weights", action="store_true",
+                    help="closed-form synthetic weights instead of the checkpoints named by the config (tests, benchmarks)")
     args = ap.parse_args(argv)
     if not args.input and not args.synthetic:
         ap.error("give --input GLOB of .npz clouds (points, normals[, labels, primitives]) or --synthetic N")
@@ -121,8 +130,8 @@ def main(argv=None):
     config = Config(args.config)
     os.environ.setdefault("CUDA_VISIBLE_DEVICES", config.gpu.split(",")[0])        # :9-11 (one process per GPU)
     device = torch.device("cuda")
-    model = build_model(config.knn, config.pretrain_model_path, 0, device, log)              # :191-193
-    model_inst = build_model(config.knn, config.pretrain_model_type_path, 1, device, log)    # :196-198
+    model = build_model(config.knn, config.pretrain_model_path, 0, device, log, args.synthetic_weights)              # :191-193
+    model_inst = build_model(config.knn, config.pretrain_model_type_path, 1, device, log, args.synthetic_weights)    # :196-198
     ms = MeanShift()
     x_all, labels_all, types_all, ids = load_clouds(args)
     if args.save == "Save":
@@ -147,11 +156,12 @@ def main(argv=None):
             cid = ids[b0 + i]
             msg = f"ID:{cid} | clusters {n_labels[i]} (passes {passes[i]})"
             gt = labels_all[b0 + i] if labels_all is not None else None
-            if gt is not None and types_all is not None:                                                 # :389-410
+            gt_types = types_all[b0 + i] if types_all is not None else None         # per cloud: an .npz may lack either
+            if gt is not None and gt_types is not None:                                                  # :389-410
                 w = torch.nn.functional.one_hot(labels[i].long(), 50).float()
                 s, p, _, _, rec = SIOU_matched_segments_usecd(np.asarray(gt).astype(np.int64), labels_h[i].astype(np.int64),
                                                               types_h[i].astype(np.int64).copy(),
-                                                              np.asarray(types_all[b0 + i]).astype(np.int64).copy(), w,
+                                                              np.asarray(gt_types).astype(np.int64).copy(), w,
                                                               x[i, 0:3].t().contiguous())
                 s_ious.append(s); p_ious.append(p); recalls.append(rec)
                 msg += f" inst_iou: {s:.4f} type_iou: {p:.4f} inst_recall: {rec:.4f}"

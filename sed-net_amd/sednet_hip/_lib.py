@@ -35,6 +35,7 @@ SIGNATURES = {
     "sed_ms_kth_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_ms_iterate_plan": (c_int, [c_int, c_int, c_int]),
     "sed_ms_iterate_ws_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "sed_ms_iterate_sparse_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P]),
     "sed_ms_iterate_bounds_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, P, P, P, c_int, c_float, P]),

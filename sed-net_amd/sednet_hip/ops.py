@@ -234,7 +234,9 @@ def ms_iterate(X, bw, iters):
                                     stream()), "ms_iterate")
     if TIMERS is not None:
         ev1.record()
-        TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
+        plan = lib.sed_ms_iterate_plan(B, N, D) if nws else 1
+        TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters),
+                                                "schedule": "split-fp16" if plan == 4 else "fp32"}))
     return out
 
 

@@ -207,3 +207,32 @@ def realistic_embedding(N=10000, d=128, n_clusters=14, sigma=0.02, bridge=0.04, 
     X[rows] = (1 - lam) * C[assign[rows]] + lam * C[other] + rng.normal(scale=sigma, size=(nb, d))
     X /= np.linalg.norm(X, axis=1, keepdims=True)
     return X.astype(F32), assign.astype(np.int64)
+
+
+def planted_embedding(labels, d=128, sigma=0.01, seed=0, guard_clouds=()):
+    """Per-point embedding that carries the segment structure of `labels` [B,N] (numpy / torch ints): unit centre per
+    (cloud, segment) + sigma noise per coordinate, built on the device of the returned tensor (cuda if available).
+    Clouds listed in `guard_clouds` get instead 60 tight clusters in 30 close pairs (unrelated to the labels): more
+    than 49 clusters at the script's quantile 0.015, the pairs merge one guard retry later (x1.2) -- the case
+    generate_predictions_aug.py:25-35 exists for. -> (X [B,N,d] fp32 unit rows, planted [B,N] int64: the partition the
+    clustering must return; for guard clouds the pair index)."""
+    import torch
+    dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    L = torch.as_tensor(np.asarray(labels)).long().to(dev)
+    B, N = L.shape
+    g = torch.Generator(device=dev).manual_seed(seed)
+    S = int(L.max()) + 1
+    C = torch.nn.functional.normalize(torch.randn(B, max(S, 60), d, generator=g, device=dev), dim=2)
+    planted = L.clone()
+    for b in guard_clouds:
+        twin = C[b, :30] + 0.04 * torch.randn(30, d, generator=g, device=dev)
+        C[b, 30:60] = torch.nn.functional.normalize(twin, dim=1)
+        a = torch.arange(N, device=dev) % 60
+        planted[b] = a % 30
+        L = L.clone(); L[b] = a
+    X = torch.gather(C, 1, L[:, :, None].expand(B, N, d))
+    sig = torch.full((B, 1, 1), float(sigma), device=dev)
+    for b in guard_clouds:
+        sig[b] = 0.002
+    X = X + sig * torch.randn(B, N, d, generator=g, device=dev)
+    return torch.nn.functional.normalize(X, dim=2).float().contiguous(), planted

@@ -12,6 +12,14 @@ import torch
 from sednet_hip import ops
 
 
+def _inference_only(t, what):
+    """The reference's mean_shift is written with differentiable torch ops (and EmbeddingLoss(if_mean_shift=True) relies
+    on it); the HIP kernels have no backward. Fail loudly instead of returning a tensor without grad_fn."""
+    if torch.is_grad_enabled() and torch.is_tensor(t) and t.requires_grad:
+        raise NotImplementedError(f"{what} runs on the HIP inference kernels and is not differentiable: call it under "
+                                  "torch.no_grad() or on a detached tensor")
+
+
 def _as_bw_tensor(b, B, device):
     if torch.is_tensor(b):
         return b.to(device=device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
@@ -26,6 +34,7 @@ class MeanShift:
     def mean_shift(self, X, num_samples, quantile, iterations, kernel_type="gaussian", bw=None, nms=True):
         """mean_shift.py:19-43 -> (new_X, center, bw, labels) or (new_X, bw) when nms=False."""
         self._check_kernel(kernel_type)
+        _inference_only(X, "MeanShift.mean_shift")
         Xp = ops.pad_features(X.detach())[None]
         d = X.shape[1]
         if bw is None:
@@ -44,6 +53,7 @@ class MeanShift:
     def mean_shift_(self, X, b, iterations=10, kernel_type="gaussian"):
         """mean_shift.py:45-79 -> (new_X, X)."""
         self._check_kernel(kernel_type)
+        _inference_only(X, "MeanShift.mean_shift_")
         Xp = ops.pad_features(X.detach())[None]
         new_X = ops.ms_iterate(Xp, _as_bw_tensor(b, 1, X.device), iterations)[0, :, :X.shape[1]]
         return new_X, X
@@ -118,30 +128,29 @@ class MeanShift:
         distributed = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         todo = np.arange(B)
         first = True
-        while True:
-            if first or not distributed:
-                if todo.size == 0:
-                    break
-                whole = todo.size == B
-                sel = None if whole else torch.as_tensor(todo, device=X.device)
-                lab_t, bw_t, nl_t = run(X if whole else X[sel], q[todo])
-            else:
+        while distributed or todo.size:
+            sel = torch.as_tensor(todo, device=X.device)
+            whole = todo.size == B and B > 0
+            if first or not distributed:                 # first pass: every rank on its own clouds
+                if todo.size:
+                    lab_t, bw_t, nl_t = run(X if whole else X[sel], q[todo])
+            else:                                        # retry passes: collective, spread over all ranks
                 from sednet_hip.shard import balanced_guard_retries
-                sel = torch.as_tensor(todo, device=X.device)
                 lab_t, bw_t, nl_t = balanced_guard_retries(X[sel], q[todo], run, dist)
                 whole = False
-            if whole:
-                labels, bw = lab_t, bw_t
-            elif todo.size:
-                labels[sel], bw[sel] = lab_t, bw_t
-            nl = nl_t.cpu().numpy()              # the one D->H sync per pass (reference: :31)
             nxt = []
-            for b_, n in zip(todo, nl):
-                n_labels[b_] = n
-                passes[b_] += 1
-                if n > max_clusters:
-                    q[b_] *= factor
-                    nxt.append(b_)
+            if todo.size:
+                if whole:
+                    labels, bw = lab_t, bw_t
+                else:
+                    labels[sel], bw[sel] = lab_t, bw_t
+                nl = nl_t.cpu().numpy()          # the one D->H sync per pass (reference: :31)
+                for b_, n in zip(todo, nl):
+                    n_labels[b_] = n
+                    passes[b_] += 1
+                    if n > max_clusters:
+                        q[b_] *= factor
+                        nxt.append(b_)
             todo = np.array(nxt, dtype=np.int64)
             first = False
             if distributed:

@@ -50,7 +50,7 @@ def test_driver_end_to_end(tmp_path):
     cfg.write_text(CFG)
     out = tmp_path / "out"
     rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--synthetic", "3", "--points", "1500",
-                  "--batch", "2", "--out", str(out)])
+                  "--batch", "2", "--out", str(out), "--synthetic-weights"])
     assert rc == 0
     for i in range(3):
         inst = np.loadtxt(out / f"{i}_inst.txt")
@@ -59,6 +59,33 @@ def test_driver_end_to_end(tmp_path):
         assert inst.shape == (1500,) and typ.shape == (1500,) and edge.shape == (1500, 2)
         assert set(np.unique(typ)) <= set(range(6)) and inst.min() == 0
         np.testing.assert_allclose(edge.sum(1), 1.0, atol=2e-4)
+
+
+def test_driver_checkpoint_and_input_contract(tmp_path):
+    """A missing checkpoint is an error like in the reference (torch.load raises there, generate_predictions_aug.py:
+    191-198) -- no silent synthetic weights; .npz inputs may carry labels without primitives (seg-IoU only), both, or
+    neither."""
+    import generate_predictions as gp
+    from sednet_hip import synth
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(CFG)
+    with pytest.raises(FileNotFoundError):
+        gp.main([str(cfg), "NoSave", "no_multi_vote", "no_fold5drop", "--synthetic", "1", "--points", "600"])
+    inp = tmp_path / "clouds"
+    inp.mkdir()
+    for i, (with_l, with_t) in enumerate([(True, False), (True, True), (False, False)]):
+        p, n, l, t = synth.synthetic_cloud(70 + i, 900, n_prims=4)
+        d = {"points": p, "normals": n}
+        if with_l:
+            d["labels"] = l
+        if with_t:
+            d["primitives"] = t
+        np.savez(inp / f"c{i}.npz", **d)
+    out = tmp_path / "out"
+    rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--input", str(inp / "*.npz"), "--batch", "3",
+                  "--out", str(out), "--synthetic-weights"])
+    assert rc == 0
+    assert sorted(f.name for f in out.iterdir()) == sorted(f"c{i}_{s}.txt" for i in range(3) for s in ("inst", "type", "edge"))
 
 
 def test_config_reader_matches_reference_keys(tmp_path):
@@ -124,7 +151,7 @@ def test_driver_with_hpnet_stage(tmp_path):
     cfg.write_text(CFG)
     out = tmp_path / "out"
     rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--synthetic", "2", "--points", "1200",
-                  "--batch", "2", "--out", str(out), "--hpnet"])
+                  "--batch", "2", "--out", str(out), "--hpnet", "--synthetic-weights"])
     assert rc == 0
     inst = np.loadtxt(out / "1_inst.txt")
     assert inst.shape == (1200,) and inst.min() == 0

@@ -256,18 +256,22 @@ def test_cylinder_against_the_noise_free_limit_and_the_reference_scatter(T, gold
         ea, ec, er = ofit.fit_cylinder_exact(p, n, w)
         a, c, r = params[i, 0:3], params[i, 3:6], params[i, 6]
         assert axis_close(a, ea, 1e-4), i
-        sgn = np.sign(np.dot(a, np.ravel(ea)))
-        np.testing.assert_allclose(c, np.ravel(ec), atol=1e-4, err_msg=str(i))
-        np.testing.assert_allclose(r, float(er), atol=1e-4, err_msg=str(i))
-        assert res[i] <= g["ref_residual"][i] + 1e-4, i
-        ax = np.ravel(g["ref_axis"][i]) / np.linalg.norm(g["ref_axis"][i])
+        ax = np.ravel(ea).astype(np.float64)
         perp = lambda v: np.ravel(v) - np.dot(np.ravel(v), ax) * ax
-        rows.append((np.abs(perp(c) - perp(g["ref_center"][i])).max(), abs(np.dot(g["ref_center"][i], ax)),
-                     abs(np.dot(c, ax)), abs(float(r) - float(g["ref_radius"][i])), g["ref_residual"][i] - res[i]))
+        rperp = lambda c_, r_: np.sqrt(max(float(r_) ** 2 - np.dot(np.ravel(c_), ax) ** 2, 0.0))
+        axr = np.ravel(g["ref_axis"][i]) / np.linalg.norm(g["ref_axis"][i])
+        perp_r = lambda v: np.ravel(v) - np.dot(np.ravel(v), axr) * axr
+        rows.append((np.abs(perp(c) - perp(ec)).max(), abs(rperp(c, r) - rperp(ec, er)), abs(np.dot(c, ax)),
+                     abs(np.dot(np.ravel(ec), ax)),
+                     np.abs(perp_r(c) - perp_r(g["ref_center"][i])).max(), abs(np.dot(g["ref_center"][i], axr)),
+                     abs(float(r) - float(g["ref_radius"][i])), g["ref_residual"][i] - res[i]))
     rows = np.array(rows)
     with capsys.disabled():
-        print("\ncylinder parity (24 segments): |dc_perp| median %.1e max %.1e; |c_par| reference max %.1e, HIP max %.1e; "
-              "|dr| max %.1e; residual(ref) - residual(HIP): min %.1e mean %.1e max %.1e"
-              % (np.median(rows[:, 0]), rows[:, 0].max(), rows[:, 1].max(), rows[:, 2].max(), rows[:, 3].max(),
-                 rows[:, 4].min(), rows[:, 4].mean(), rows[:, 4].max()))
-    assert rows[:, 2].max() < 1e-3 and rows[:, 4].min() > -1e-4
+        print("\ncylinder parity (24 segments). HIP vs noise-free limit: |dc_perp| max %.1e, |dr_perp| max %.1e, |c_par| HIP max "
+              "%.1e / limit max %.1e. HIP vs reference: |dc_perp| median %.1e max %.1e, |c_par| reference max %.1e, |dr| max "
+              "%.1e, residual(ref) - residual(HIP): min %.1e mean %.1e max %.1e"
+              % (rows[:, 0].max(), rows[:, 1].max(), rows[:, 2].max(), rows[:, 3].max(), np.median(rows[:, 4]),
+                 rows[:, 4].max(), rows[:, 5].max(), rows[:, 6].max(), rows[:, 7].min(), rows[:, 7].mean(), rows[:, 7].max()))
+    assert rows[:, 0].max() < 1e-4 and rows[:, 1].max() < 1e-4          # well-posed part: equals the limit
+    assert rows[:, 2].max() < 1e-3                                      # axial centre: ~0 (the reference: up to 0.19)
+    assert rows[:, 7].min() > -1e-4                                     # never worse in the reference's own residual

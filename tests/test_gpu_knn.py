@@ -130,3 +130,25 @@ def test_subsampled_first_sweep_stays_exact(T, k):
         ops.FUSED_KNN = True
     assert T.equal(a, b)
     assert fused["fused"] == 1 and fused["fallback"] == 0
+
+
+def test_graph_feature_surface_matches_reference(T, golden):
+    """the standalone get_graph_feature surface (PointNet.py:140-171) against the tensor the reference
+    itself produced (f_knn.feat_out): given the reference's indices the gather is pure data movement -> bit exact; with
+    its own kNN the indices (and then the tensor) agree as well on this tie-free case; _with_normals goes through the
+    xyz-normal metric and must equal the plain gather on ITS indices."""
+    from src.PointNet import get_graph_feature, get_graph_feature_with_normals, knn_points_normals
+    g = golden("f_knn")
+    x = dev(T, g["feat_x"])                                             # [1, 8, 64]
+    ref_idx = T.from_numpy(g["feat_idx"].astype(np.int64)).cuda()
+    out = get_graph_feature(x, 4, 4, idx=ref_idx)
+    assert tuple(out.shape) == tuple(g["feat_out"].shape) and out.is_contiguous()
+    np.testing.assert_array_equal(out.cpu().numpy(), g["feat_out"])
+    own = get_graph_feature(x, 4, 4)
+    np.testing.assert_array_equal(own.cpu().numpy(), g["feat_out"])
+    x6 = dev(T, g["x_a"])                                               # [1, 6, 512] xyz + normals
+    idx = knn_points_normals(x6, 20, 20, 1.0)
+    a = get_graph_feature_with_normals(x6, 20, 20, normal_metric_W=1.0)
+    b = get_graph_feature(x6, 20, 20, idx=idx)
+    assert T.equal(a, b) and tuple(a.shape) == (1, 12, 512, 20)
+    np.testing.assert_array_equal(a[0, 6:, :, 0].cpu().numpy(), g["x_a"][0])          # second half = the centre point

@@ -103,3 +103,28 @@ def test_seg_iou_metric_with_chamfer_recall_matches_reference(T, golden):
     np.testing.assert_array_equal(matching[0][1], g["m_cols"])
     np.testing.assert_allclose([s_iou, p_iou, recall], g["m_result"], rtol=1e-6)
     assert 0 < recall <= 1 and len(pairs) > 0
+
+
+def test_differentiable_operators_have_gradients(T):
+    """gather / grouping / three_interpolate return tensors with a grad_fn: the backward is the scatter-add of
+    group_points_gpu.cu:47-80 / interpolate_gpu.cu:111-148; checked against torch indexing under autograd."""
+    from pointnet2 import pointnet2_utils as pu
+    g = T.Generator().manual_seed(0)
+    B, C, N, m, ns = 2, 5, 40, 9, 4
+    f = T.randn(B, C, N, generator=g).cuda().requires_grad_(True)
+    idx1 = T.randint(0, N, (B, m), generator=g).int().cuda()
+    idx2 = T.randint(0, N, (B, m, ns), generator=g).int().cuda()
+    idx3 = T.randint(0, N, (B, 12, 3), generator=g).int().cuda()
+    w3 = T.rand(B, 12, 3, generator=g).cuda()
+    cot1, cot2, cot3 = (T.randn(s, generator=g).cuda() for s in ((B, C, m), (B, C, m, ns), (B, C, 12)))
+    loss = (pu.gather_operation(f, idx1) * cot1).sum() + (pu.grouping_operation(f, idx2) * cot2).sum() \
+        + (pu.three_interpolate(f, idx3, w3) * cot3).sum()
+    loss.backward()
+    got = f.grad.clone()
+    f2 = f.detach().clone().requires_grad_(True)
+    bi = T.arange(B, device="cuda")[:, None]
+    ga = f2[bi, :, idx1.long()].permute(0, 2, 1)
+    gr = f2[bi[:, :, None], :, idx2.long()].permute(0, 3, 1, 2)
+    it = (f2[bi[:, :, None], :, idx3.long()] * w3[..., None]).sum(2).permute(0, 2, 1)
+    ((ga * cot1).sum() + (gr * cot2).sum() + (it * cot3).sum()).backward()
+    np.testing.assert_allclose(got.cpu().numpy(), f2.grad.cpu().numpy(), atol=1e-5)

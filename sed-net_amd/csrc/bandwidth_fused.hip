@@ -14,6 +14,7 @@
 // Distances are 2 - 2 s with s the same fp32 MFMA chain as pair_dist_kernel<NT, MODE_MS>, so the K-th values are
 // bit-identical to the materialised path. A list overflow raises a flag and the caller re-runs the materialised path.
 #include "common.h"
+#include "split16.h"
 
 namespace {
 
@@ -21,8 +22,10 @@ constexpr int BM = 8;             // minima kept per bucket in sweep 1
 constexpr int CAPK = 256;         // candidates per lane (two lanes per query)
 constexpr int KMAX = 160;
 
-template <int NT, int PASS>
-__global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, int N, int K,
+// F16 (d = 64 / 128): split-fp16 dot products on the pre-split row image (split16.h), like knn_fused.hip.
+template <int NT, int PASS, bool F16>
+__global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, const float* __restrict__ inv,
+                                                              int N, int K,
                                                               uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ lists,
                                                               int* __restrict__ counts, int* __restrict__ overflow) {
     constexpr int D = 32 * NT;
@@ -37,16 +40,26 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int ntiles = (N + 31) >> 5;
 
-    float q[NT][16];
+    float q[F16 ? 1 : NT][16];
+    h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
+    float two_cq = 2.0f;
+    __shared__ float cks[2][32];
+    const float* invc = F16 ? inv + (size_t)cloud * N : nullptr;
+    if (F16) {
+        split_load_query<NT>((const h16*)Xc + (size_t)qrow_c * 2 * D, hi, qh, ql);
+        two_cq = 2.0f * invc[qrow_c];
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
-        }
+                for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+            }
+    }
     f32x4 stage[NT];
+    float stage_ck = 0.f;
     auto stage_load = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -57,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
             if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
             stage[u] = v;
         }
+        if (F16 && tid < 32) { const int key = tile * 32 + tid; stage_ck = key < N ? invc[key] : 0.f; }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -65,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
             const int row = i / C4, c4 = i % C4;
             *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
         }
+        if (F16 && tid < 32) cks[buf][tid] = stage_ck;
     };
 
     uint32_t bm[PASS == 1 ? BM : 1][16];
@@ -91,20 +106,25 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         if (tile + tstep < ntiles) stage_load(tile + tstep);
         const float* xt = lds[cur];
         f32x16 s;
+        if (F16) {
+            s = split_tile_keys_on_rows<NT>((const uint8_t*)(xt + li * LDX), hi, qh, ql);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
-            }
+                    for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
+                }
+        }
         const bool ragged = (tile == ntiles - 1) && (N & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float dv = 2.0f - 2.0f * s[r];                                         // mean_shift.py:128
+            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][mfma_row(r, hi)] : 2.0f * s[r];
+            const float dv = 2.0f - dot2;                                                // mean_shift.py:128
             uint32_t key = f32_sortable(dv);
             if (ragged && tile * 32 + mfma_row(r, hi) >= N) key = 0xFFFFFFFFu;
             if (PASS == 1) {
@@ -175,21 +195,30 @@ __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __
     if (lane == 0) kth[row] = sortable_f32(lo);
 }
 
-struct KWs { uint32_t* T; int* counts; uint32_t* lists; };
+struct KWs { uint32_t* T; int* counts; uint32_t* lists; float* inv; h16* img; };
 KWs kcarve(void* ws, int B, int N) {
     const size_t bn = (size_t)B * N;
     KWs w;
     w.T = (uint32_t*)ws;
     w.counts = (int*)(w.T + bn);
     w.lists = (uint32_t*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
+    w.inv = (float*)(w.lists + bn * 2 * CAPK);
+    w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
     return w;
 }
 
 template <int NT>
 void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, hipStream_t s) {
     const dim3 grid((N + 127) / 128, B);
-    ms_kth_sweep_kernel<NT, 1><<<grid, 256, 0, s>>>(X, N, K, w.T, w.lists, w.counts, overflow);
-    ms_kth_sweep_kernel<NT, 2><<<grid, 256, 0, s>>>(X, N, K, w.T, w.lists, w.counts, overflow);
+    constexpr bool F16 = NT == 2 || NT == 4;
+    if (F16) {
+        constexpr int D = F16 ? 32 * NT : 64;
+        const size_t rows = (size_t)B * N;
+        split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
+        X = (const float*)w.img;
+    }
+    ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
 }
 
 }  // namespace
@@ -198,7 +227,8 @@ extern "C" int sed_ms_kth_fused_max_k(void) { return KMAX; }
 
 extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
-    return bn * sizeof(uint32_t) + bn * 2 * sizeof(int) + bn * 2 * CAPK * sizeof(uint32_t) + 256;
+    return bn * sizeof(uint32_t) + bn * 2 * sizeof(int) + bn * 2 * CAPK * sizeof(uint32_t) + 256 +
+           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 256;
 }
 
 // X [B,N,d] unit rows, d in {32, 64, 96, 128} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j

@@ -14,6 +14,7 @@
 // Work: 2 x 2 N^2 C flops on the fp32 MFMA + N * (CAP lists) bytes, instead of 2 x N^2 x 4 bytes of HBM traffic
 // and a 32-step bisection per row.
 #include "common.h"
+#include "split16.h"
 
 namespace {
 
@@ -22,8 +23,11 @@ constexpr int CAPL = 96;          // candidates per lane (two lanes per query)
 struct Cand { uint32_t key; int idx; };
 
 // ---- feature-space metric (MFMA) --------------------------------------------------------------------------
-template <int NT, int M, int PASS>
+// F16: the dot products run on the fp16 matrix pipe through the split-fp16 evaluation of split16.h (X = the row image,
+// same bytes per row as the fp32 row; inv = the rows' 2^-e); otherwise exact fp32 MFMA chains on X itself.
+template <int NT, int M, int PASS, bool F16>
 __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restrict__ X, const float* __restrict__ xx,
+                                                           const float* __restrict__ inv,
                                                            int N, int k, uint32_t* __restrict__ Tbuf,
                                                            Cand* __restrict__ lists, int* __restrict__ counts,
                                                            int* __restrict__ overflow) {
@@ -42,19 +46,28 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int ntiles = (N + 31) >> 5;
 
-    float q[NT][16];
+    float q[F16 ? 1 : NT][16];
+    h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
+    float two_cq = 2.0f;                                   // 2 * 2^-e of the query row (F16), else 2
+    if (F16) {
+        split_load_query<NT>((const h16*)Xc + (size_t)qrow_c * 2 * D, hi, qh, ql);
+        two_cq = 2.0f * inv[(size_t)cloud * N + qrow_c];
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
-        }
+                for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+            }
+    }
     const float xq = xxc[qrow_c];
+    const float* invc = F16 ? inv + (size_t)cloud * N : nullptr;
+    __shared__ float cks[2][32];                           // 2^-e of the staged key rows (F16)
 
     f32x4 stage[NT];
-    float stage_xx = 0.f;
+    float stage_xx = 0.f, stage_ck = 0.f;
     auto stage_load = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -65,7 +78,11 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
             if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
             stage[u] = v;
         }
-        if (tid < 32) { const int key = tile * 32 + tid; stage_xx = key < N ? xxc[key] : 0.f; }
+        if (tid < 32) {
+            const int key = tile * 32 + tid;
+            stage_xx = key < N ? xxc[key] : 0.f;
+            if (F16) stage_ck = key < N ? invc[key] : 0.f;
+        }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
             const int row = i / C4, c4 = i % C4;
             *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
         }
-        if (tid < 32) xxs[buf][tid] = stage_xx;
+        if (tid < 32) { xxs[buf][tid] = stage_xx; if (F16) cks[buf][tid] = stage_ck; }
     };
 
     uint32_t bm[M][16];
@@ -105,22 +122,27 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
         if (tile + tstep < ntiles) stage_load(tile + tstep);
         const float* xt = lds[cur];
         f32x16 s;
+        if (F16) {
+            s = split_tile_keys_on_rows<NT>((const uint8_t*)(xt + li * LDX), hi, qh, ql);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
-            }
+                    for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);      // keys on rows, queries on lanes
+                }
+        }
         const bool ragged = (tile == ntiles - 1) && (N & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int krow = mfma_row(r, hi);
             const float xk = xxs[cur][krow];
-            const float t1 = __fadd_rn(-xk, 2.0f * s[r]);        // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
+            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][krow] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
+            const float t1 = __fadd_rn(-xk, dot2);               // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
             const float dv = -__fsub_rn(t1, xq);                 // ... - xx_i ; distance = -score
             uint32_t key = f32_sortable(dv);
             if (ragged && tile * 32 + krow >= N) key = 0xFFFFFFFFu;
@@ -287,7 +309,8 @@ int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 
 extern "C" size_t sed_knn_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
     return bn * sizeof(float) /*xx*/ + bn * sizeof(uint32_t) /*T*/ + bn * 2 * sizeof(int) /*counts*/ +
-           bn * 2 * CAPL * sizeof(Cand) + 256;
+           bn * 2 * CAPL * sizeof(Cand) + 256 +
+           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image, d <= 128*/ + 256;
 }
 extern "C" int sed_knn_fused_max_k(void) { return 85; }
 
@@ -301,7 +324,7 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
                                     size_t ws_bytes, int* overflow, hipStream_t stream);
 
 namespace {
-struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; };
+struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; float* inv; h16* img; };
 Ws carve(void* ws, int B, int N) {
     const size_t bn = (size_t)B * N;
     Ws w;
@@ -309,6 +332,8 @@ Ws carve(void* ws, int B, int N) {
     w.T = (uint32_t*)(w.xx + bn);
     w.counts = (int*)(w.T + bn);
     w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
+    w.inv = (float*)(((uintptr_t)(w.lists + bn * 2 * CAPL) + 15) & ~(uintptr_t)15);
+    w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
     return w;
 }
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows,
@@ -316,10 +341,18 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X
     __shared__ float tile[256 * 33];
     sed_row_sqnorm_block(X, xx, rows, D, C, tile);
 }
+// d = 64 and d = 128 (the widths SED-Net uses) take the split-fp16 products; the row image is built once per call
 template <int NT, int M>
 void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {
-    knn_sweep_kernel<NT, M, 1><<<grid, 256, 0, s>>>(X, w.xx, N, k, w.T, w.lists, w.counts, overflow);
-    knn_sweep_kernel<NT, M, 2><<<grid, 256, 0, s>>>(X, w.xx, N, k, w.T, w.lists, w.counts, overflow);
+    constexpr bool F16 = NT == 2 || NT == 4;
+    if (F16) {
+        constexpr int D = F16 ? 32 * NT : 64;
+        const size_t rows = (size_t)grid.y * N;
+        split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
+        X = (const float*)w.img;
+    }
+    knn_sweep_kernel<NT, M, 1, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+    knn_sweep_kernel<NT, M, 2, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
 }
 template <int NT>
 int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {

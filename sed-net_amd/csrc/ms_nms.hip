@@ -10,13 +10,17 @@
 // plus the number of distinct labels used, which the caller's guard loop needs
 // (generate_predictions_aug.py:31).
 #include "common.h"
+#include "split16.h"
 
 namespace {
 
 // ---- 1. membership: streaming argmin over all centres, MFMA products as in ms_iterate.hip --------
-template <int NT>
+// F16 (d = 64 / 128): C and X are split-fp16 row images (split16.h), cinv / xinv the rows' 2^-e.
+template <int NT, bool F16>
 __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restrict__ C,   // centres [B,N,D]
                                                             const float* __restrict__ X,   // points  [B,N,D]
+                                                            const float* __restrict__ cinv,
+                                                            const float* __restrict__ xinv,
                                                             int* __restrict__ member, int N) {
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
@@ -31,16 +35,26 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
     const int prow_c = prow < N ? prow : N - 1;
     const int ntiles = (N + 31) >> 5;
 
-    float q[NT][16];
+    float q[F16 ? 1 : NT][16];
+    h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
+    float two_cq = 2.0f;
+    __shared__ float cks[2][32];
+    const float* cinvc = F16 ? cinv + (size_t)cloud * N : nullptr;
+    if (F16) {
+        split_load_query<NT>((const h16*)Xc + (size_t)prow_c * 2 * D, hi, qh, ql);
+        two_cq = 2.0f * xinv[(size_t)cloud * N + prow_c];
+    } else {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = *(const f32x4*)(Xc + (size_t)prow_c * D + 32 * t + 8 * g + 4 * hi);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = *(const f32x4*)(Xc + (size_t)prow_c * D + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
-        }
+                for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+            }
+    }
     f32x4 stage[NT];
+    float stage_ck = 0.f;
     auto stage_load = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -51,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
             if (key < N) v = *(const f32x4*)(Cc + (size_t)key * D + 4 * c4);
             stage[u] = v;
         }
+        if (F16 && tid < 32) { const int key = tile * 32 + tid; stage_ck = key < N ? cinvc[key] : 0.f; }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -59,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
             const int row = i / C4, c4 = i % C4;
             *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
         }
+        if (F16 && tid < 32) cks[buf][tid] = stage_ck;
     };
     stage_load(0);
     stage_store(0);
@@ -70,20 +86,25 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
         if (tile + 1 < ntiles) stage_load(tile + 1);
         const float* xt = lds[cur];
         f32x16 s;
+        if (F16) {
+            s = split_tile_keys_on_rows<NT>((const uint8_t*)(xt + li * LDX), hi, qh, ql);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);   // centres on rows, points on lanes
-            }
+                    for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);   // centres on rows, points on lanes
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = tile * 32 + mfma_row(r, hi);
-            const float dist = 2.0f - 2.0f * s[r];
+            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][mfma_row(r, hi)] : 2.0f * s[r];
+            const float dist = 2.0f - dot2;
             if (ci < N && (dist < best || (dist == best && ci < besti))) { best = dist; besti = ci; }
         }
         if (tile + 1 < ntiles) stage_store(cur ^ 1);
@@ -295,8 +316,10 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const int* __restrict_
 }  // namespace
 
 extern "C" size_t sed_ms_nms_workspace_bytes(int B, int N) {
-    // member, counts, uniq, voted, used : 5 int arrays [B,N] ; n_uniq [B]
-    return (size_t)B * N * 5 * sizeof(int) + (size_t)B * sizeof(int);
+    // member, counts, uniq, voted, used : 5 int arrays [B,N] ; n_uniq [B] ; split-fp16 row images of the centres and the
+    // points (d <= 128) + their row scales for the membership products
+    return (size_t)B * N * 5 * sizeof(int) + (size_t)B * sizeof(int) + 512 +
+           2 * ((size_t)B * N * sizeof(float) + (size_t)B * N * 128 * sizeof(float) + 256);
 }
 
 // centres = converged new_X [B,N,d]; X [B,N,d]; bw [B]. Outputs: labels [B,N] int32 (0..m-1, ordered by
@@ -322,12 +345,28 @@ extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const f
     if (e != hipSuccess) return (int)e;
 
     dim3 g1((N + 127) / 128, B);
-    switch (d / 32) {
-        case 1: membership_kernel<1><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
-        case 2: membership_kernel<2><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
-        case 3: membership_kernel<3><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
-        case 4: membership_kernel<4><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
-        case 5: membership_kernel<5><<<g1, 256, 0, stream>>>(centres, X, member, N); break;
+    if (d == 64 || d == 128) {
+        // membership products on the fp16 matrix pipe (split16.h): split the centres and the points once
+        float* cinv = (float*)(((uintptr_t)(n_uniq + B) + 255) & ~(uintptr_t)255);
+        h16* cimg = (h16*)(((uintptr_t)(cinv + bn) + 255) & ~(uintptr_t)255);
+        float* xinv = (float*)(cimg + bn * 2 * 128);
+        h16* ximg = (h16*)(((uintptr_t)(xinv + bn) + 255) & ~(uintptr_t)255);
+        const unsigned nb = (unsigned)((bn * (d / 4) + 255) / 256);
+        if (d == 64) {
+            split_rows_kernel<64><<<nb, 256, 0, stream>>>(centres, cimg, cinv, bn);
+            split_rows_kernel<64><<<nb, 256, 0, stream>>>(X, ximg, xinv, bn);
+            membership_kernel<2, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N);
+        } else {
+            split_rows_kernel<128><<<nb, 256, 0, stream>>>(centres, cimg, cinv, bn);
+            split_rows_kernel<128><<<nb, 256, 0, stream>>>(X, ximg, xinv, bn);
+            membership_kernel<4, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N);
+        }
+    } else {
+        switch (d / 32) {
+            case 1: membership_kernel<1, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
+            case 3: membership_kernel<3, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
+            case 5: membership_kernel<5, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
+        }
     }
     SED_LAUNCH_CHECK();
     count_members_kernel<<<dim3((N + 255) / 256, B), 256, 0, stream>>>(member, counts, N);

@@ -11,7 +11,11 @@
 // (lanes = consecutive keys). This is the round-1 form: HBM-bound on 2 * N^2 * 4 bytes per cloud
 // (write here, read in select); a fused streaming top-k that never materialises D is the planned
 // replacement.
+// Round 2: for the widths the streaming kernels evaluate in split-fp16 (d = 64, d = 128; split16.h) this kernel does the
+// same -- rows are split while they are staged, with the same per-row scale -- so that the materialised fall-back stays
+// bit-identical to the streaming path (tests/test_gpu_knn.py, tests/test_gpu_mean_shift.py).
 #include "common.h"
+#include "split16.h"
 
 namespace {
 
@@ -39,15 +43,49 @@ __global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restri
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int ntiles = (N + 31) >> 5;
 
-    float q[NT][16];
+    constexpr bool F16 = NT == 2 || NT == 4;
+    __shared__ float cks[2][32];                  // 2^-e of the staged key rows
+    __shared__ float cqs[128];                    // 2^-e of this workgroup's query rows
+    float q[F16 ? 1 : NT][16];
+    h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
+    float cq[16];
+    if (F16) {
+        // query row as the A operand (queries on accumulator rows): k-step ks holds features 16 ks + 8 hi .. + 8
+        f32x4 v[4 * NT];
+        float am = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int ks = 0; ks < 2 * NT; ++ks)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+            for (int g = 0; g < 2; ++g) {
+                v[2 * ks + g] = *(const f32x4*)(Xc + (size_t)qrow_c * D + 16 * ks + 8 * hi + 4 * g);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
-        }
+                for (int c = 0; c < 4; ++c) am = fmaxf(am, fabsf(v[2 * ks + g][c]));
+            }
+        am = fmaxf(am, xor32(am));
+        const float scale = split_row_scale(am);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                h16 a, b;
+                split_pair(v[2 * ks + (i >> 2)][i & 3], scale, a, b);
+                qh[ks][i] = a;
+                ql[ks][i] = b;
+            }
+        if (hi == 0) cqs[wave * 32 + li] = 1.0f / scale;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cq[r] = cqs[wave * 32 + mfma_row(r, hi)];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) q[t][4 * g + c] = v[c];
+            }
+    }
     float xq[16];
     if (MODE == MODE_KNN) {
 #pragma unroll
@@ -74,7 +112,23 @@ __global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restri
         for (int u = 0; u < NT; ++u) {
             const int i = tid + 256 * u;
             const int row = i / C4, c4 = i % C4;
-            *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+            if (F16) {
+                // the C4 (16 / 32) consecutive lanes that hold this row agree on its scale, then split their 4 values
+                const f32x4 v = stage[u];
+                float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+                for (int off = C4 / 2; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+                const float scale = split_row_scale(am);
+                h16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h16 a, b; split_pair(v[e], scale, a, b); h[e] = a; l[e] = b; }
+                h16* rowp = (h16*)&lds[buf][row * LDX];
+                *(h16x4*)(rowp + 4 * c4) = h;
+                *(h16x4*)(rowp + D + 4 * c4) = l;
+                if (c4 == 0) cks[buf][row] = 1.0f / scale;
+            } else {
+                *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
+            }
         }
     };
 
@@ -89,27 +143,42 @@ __global__ __launch_bounds__(256, 2) void pair_dist_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         // S = Q . X_tile^T : queries on accumulator rows, keys on lanes (coalesced stores)
+        if (F16) {
+            // same products in the same order as split_tile_keys_on_rows (l_key h_query, h_key l_query, h_key h_query)
+            const uint8_t* krow = (const uint8_t*)(xt + li * LDX);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) s = mfma32(q[t][4 * g + c], xa[c], s);
+            for (int ks = 0; ks < 2 * NT; ++ks) {
+                const h16x8 xh = *(const h16x8*)(krow + ks * 32 + hi * 16);
+                const h16x8 xl = *(const h16x8*)(krow + 2 * D + ks * 32 + hi * 16);
+                s = mfma16(qh[ks], xl, s);
+                s = mfma16(ql[ks], xh, s);
+                s = mfma16(qh[ks], xh, s);
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xa = *(const f32x4*)(xt + li * LDX + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s = mfma32(q[t][4 * g + c], xa[c], s);
+                }
+        }
         const int key = tile * 32 + li;
         if (key < N) {
             float xk = 0.f;
             if (MODE == MODE_KNN) xk = xxc[key];
+            const float ck = F16 ? cks[cur][li] : 1.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = q0 + mfma_row(r, hi);
                 if (row < N) {
                     float dv;
+                    const float dot2 = F16 ? (s[r] * (2.0f * cq[r])) * ck : 2.0f * s[r];
                     if (MODE == MODE_MS) {
-                        dv = 2.0f - 2.0f * s[r];
+                        dv = 2.0f - dot2;
                     } else {
-                        const float t1 = __fadd_rn(-xk, 2.0f * s[r]);   // (-xx_j) - inner,  inner = -2 dot
+                        const float t1 = __fadd_rn(-xk, dot2);          // (-xx_j) - inner,  inner = -2 dot
                         dv = -__fsub_rn(t1, xq[r]);                     //  ... - xx_i ; D = -score
                     }
                     Dc[(size_t)row * ldD + key] = dv;

@@ -1,0 +1,94 @@
+// Split-fp16 evaluation of fp32 dot products on v_mfma_f32_32x32x16_f16 (shared by the selection kernels).
+//
+// A row x (D fp32 values) is stored as two fp16 planes of x * 2^e, e chosen PER ROW from the row's own largest magnitude:
+//     x 2^e = h + l + err,   h = fp16(x 2^e),  l = fp16(x 2^e - h),   |err| <= 2^-24 |x 2^e|  (round to nearest twice)
+// with 2^13 <= max|x 2^e| < 2^14 (so h never overflows and l stays a normal fp16 number for every element within 2^-13 of
+// the row's largest; smaller elements lose relative, not absolute, accuracy: <= 2^-25 in scaled units = 2^-38 of the row max).
+// A dot product x.y is evaluated as  l_x.h_y + h_x.l_y + h_x.h_y  -- three fp16 MFMAs per 16 features, products of two fp16
+// numbers are exact in the MFMA's fp32 accumulator -- and unscaled by the exact power of two 2^-(e_x + e_y). What is dropped
+// (l_x.l_y and err) is <= 3 * 2^-24 of |x||y| per product: one fp32 rounding, where the fp32 fma chain it replaces rounds D
+// times. 3 fp16 MFMAs (32 cycles each per 16 features) instead of 8 fp32 ones (64 cycles each per 2 features): 5.3 x less
+// matrix time. The split is a deterministic function of the row alone, so every kernel that uses it -- the streaming sweeps on
+// pre-split images and the materialised fall-back kernels that split while staging -- produces bit-identical scores.
+#pragma once
+#include "common.h"
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// scale 2^e for a row whose largest magnitude is amax: amax * 2^e in [2^13, 2^14); 1 for zero / non-finite rows
+__device__ __forceinline__ float split_row_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    int ex;
+    (void)frexpf(amax, &ex);                     // amax = m 2^ex, m in [0.5, 1)
+    int e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.0f, e);
+}
+
+__device__ __forceinline__ void split_pair(float v, float scale, h16& h, h16& l) {
+    const float s = v * scale;
+    h = (h16)s;
+    l = (h16)(s - (float)h);
+}
+
+// Row image: [row][ h plane: D halves | l plane: D halves ] (4 D bytes, the size of the fp32 row) + inv[row] = 2^-e.
+// One thread per float4 of a row; D / 4 consecutive threads (16 or 32: D = 64 / 128) own one row.
+template <int D>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, h16* __restrict__ img,
+                                                         float* __restrict__ inv, size_t rows) {
+    constexpr int C4 = D / 4;
+    static_assert(C4 == 16 || C4 == 32, "rows must be owned by a power-of-two lane group inside one wave");
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = i / C4;
+    const int c4 = (int)(i % C4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) v = *(const f32x4*)(X + row * D + 4 * c4);
+    float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int off = C4 / 2; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    const float scale = split_row_scale(am);
+    if (row >= rows) return;
+    h16x4 h, l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h16 a, b; split_pair(v[u], scale, a, b); h[u] = a; l[u] = b; }
+    *(h16x4*)(img + row * 2 * D + 4 * c4) = h;
+    *(h16x4*)(img + row * 2 * D + D + 4 * c4) = l;
+    if (c4 == 0) inv[row] = 1.0f / scale;
+}
+
+// S^T tile (32 keys on accumulator rows x 32 queries on lanes) from a staged key tile and the query planes in registers.
+// `krow` = this lane's key row in LDS (row li of the tile), 4 D bytes: h plane then l plane; qh / ql: the lane's query row,
+// k-step ks holds features 16 ks + 8 hi .. + 8.  Same instruction sequence everywhere => identical bits everywhere.
+template <int NT>
+__device__ __forceinline__ f32x16 split_tile_keys_on_rows(const uint8_t* krow, int hi, const h16x8* qh, const h16x8* ql) {
+    constexpr int D = 32 * NT;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+        const h16x8 xh = *(const h16x8*)(krow + ks * 32 + hi * 16);
+        const h16x8 xl = *(const h16x8*)(krow + 2 * D + ks * 32 + hi * 16);
+        s = mfma16(xl, qh[ks], s);
+        s = mfma16(xh, ql[ks], s);
+        s = mfma16(xh, qh[ks], s);
+    }
+    return s;
+}
+
+// query planes of one image row (global memory) in the B-operand layout of the product above
+template <int NT>
+__device__ __forceinline__ void split_load_query(const h16* img_row, int hi, h16x8* qh, h16x8* ql) {
+    constexpr int D = 32 * NT;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+        qh[ks] = *(const h16x8*)(img_row + 16 * ks + 8 * hi);
+        ql[ks] = *(const h16x8*)(img_row + D + 16 * ks + 8 * hi);
+    }
+}

@@ -61,6 +61,15 @@ int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* id
                       int* overflow, sed_stream_t stream);
 int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws, size_t ws_bytes,
                          int* overflow, sed_stream_t stream);
+/* the k FARTHEST points per row (same selection on negated distances; farthest first, ties -> lowest index).
+ * Replaces knn_idx (square_distance(...).topk(k), largest)            src/smooth_normal_matrix.py:33-40 */
+int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
+                          int* overflow, sed_stream_t stream);
+/* Y [B,N,ncol] = M X, M = B matrices in CSR sharing the entry capacity nnz_stride (rowptr [B,N+1], col / val
+ * [B,nnz_stride]); ncol in {4,8,12,16,24,36}. The sparse part of the HPNet affinity operator (one wave per row,
+ * deterministic).                                                       src/smooth_normal_matrix.py:42-92, :198 */
+int sed_csr_spmm_f32(int B, int N, int ncol, size_t nnz_stride, const int* rowptr, const int* col, const float* val,
+                     const float* X, float* Y, sed_stream_t stream);
 
 /* ---- mean-shift clustering --------------------------------------------------------------------------- */
 /* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
                                                            const float* __restrict__ inv,
                                                            int N, int k, uint32_t* __restrict__ Tbuf,
                                                            Cand* __restrict__ lists, int* __restrict__ counts,
-                                                           int* __restrict__ overflow) {
+                                                           int* __restrict__ overflow, int far) {
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
             const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][krow] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
             const float t1 = __fadd_rn(-xk, dot2);               // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
             const float dv = -__fsub_rn(t1, xq);                 // ... - xx_i ; distance = -score
-            uint32_t key = f32_sortable(dv);
+            uint32_t key = f32_sortable(far ? -dv : dv);         // far: the k LARGEST distances (smooth_normal_matrix.py:33-40)
             if (ragged && tile * 32 + krow >= N) key = 0xFFFFFFFFu;
             if (PASS == 1) {
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X
 }
 // d = 64 and d = 128 (the widths SED-Net uses) take the split-fp16 products; the row image is built once per call
 template <int NT, int M>
-void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {
+void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, int far, hipStream_t s) {
     constexpr bool F16 = NT == 2 || NT == 4;
     if (F16) {
         constexpr int D = F16 ? 32 * NT : 64;
@@ -351,24 +351,39 @@ void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* ov
         split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
         X = (const float*)w.img;
     }
-    knn_sweep_kernel<NT, M, 1, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
-    knn_sweep_kernel<NT, M, 2, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+    knn_sweep_kernel<NT, M, 1, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow, far);
+    knn_sweep_kernel<NT, M, 2, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow, far);
 }
 template <int NT>
-int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, hipStream_t s) {
+int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, int far, hipStream_t s) {
     switch (M) {
-        case 1: launch_sweeps<NT, 1>(grid, X, w, N, k, overflow, s); break;
-        case 2: launch_sweeps<NT, 2>(grid, X, w, N, k, overflow, s); break;
-        case 3: launch_sweeps<NT, 3>(grid, X, w, N, k, overflow, s); break;
-        case 4: launch_sweeps<NT, 4>(grid, X, w, N, k, overflow, s); break;
+        case 1: launch_sweeps<NT, 1>(grid, X, w, N, k, overflow, far, s); break;
+        case 2: launch_sweeps<NT, 2>(grid, X, w, N, k, overflow, far, s); break;
+        case 3: launch_sweeps<NT, 3>(grid, X, w, N, k, overflow, far, s); break;
+        case 4: launch_sweeps<NT, 4>(grid, X, w, N, k, overflow, far, s); break;
         default: return SED_EUNSUPPORTED;
     }
     return SED_OK;
 }
 }  // namespace
 
+static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
+                          int* overflow, int far, hipStream_t stream);
+
 extern "C" int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
                                  size_t ws_bytes, int* overflow, hipStream_t stream) {
+    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 0, stream);
+}
+
+// Same selection on the NEGATED distances: idx [B,N,k] = the k FARTHEST points of every row, farthest first (ties ->
+// lowest index). Replaces knn_idx of src/smooth_normal_matrix.py:33-40 (square_distance(...).topk(k) -- largest).
+extern "C" int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
+                                     size_t ws_bytes, int* overflow, hipStream_t stream) {
+    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 1, stream);
+}
+
+static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
+                          int* overflow, int far, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || k > N || !X || !idx || !ws || !overflow || C > d) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 128 || k > 85) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_knn_fused_workspace_bytes(B, N)) return SED_EINVAL;
@@ -382,10 +397,10 @@ extern "C" int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float*
     const int M = pick_M(k);
     int rc;
     switch (d / 32) {
-        case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, stream); break;
-        case 2: rc = launch_nt<2>(grid, M, X, w, N, k, overflow, stream); break;
-        case 3: rc = launch_nt<3>(grid, M, X, w, N, k, overflow, stream); break;
-        default: rc = launch_nt<4>(grid, M, X, w, N, k, overflow, stream); break;
+        case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, far, stream); break;
+        case 2: rc = launch_nt<2>(grid, M, X, w, N, k, overflow, far, stream); break;
+        case 3: rc = launch_nt<3>(grid, M, X, w, N, k, overflow, far, stream); break;
+        default: rc = launch_nt<4>(grid, M, X, w, N, k, overflow, far, stream); break;
     }
     if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();

@@ -29,6 +29,8 @@ SIGNATURES = {
     "sed_knn_fused_max_k": (c_int, []),
     "sed_knn_fused_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_knn_pn_fused_f32": (c_int, [c_int, c_int, c_int, c_float, P, P, P, c_size_t, P, P]),
+    "sed_knn_fused_far_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
+    "sed_csr_spmm_f32": (c_int, [c_int, c_int, c_int, c_size_t, P, P, P, P, P, P]),
     "sed_ms_bandwidth_finalize_f32": (c_int, [c_int, c_int, c_float, P, P, P]),
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_kth_fused_max_k": (c_int, []),

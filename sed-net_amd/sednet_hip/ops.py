@@ -82,6 +82,29 @@ def knn_features(X, k, C=None):
     return idx
 
 
+def knn_farthest(P, k):
+    """The k FARTHEST points of every row (Euclidean): P [B,N,c] (c <= 32) -> idx [B,N,k] int32, farthest first
+    (src/smooth_normal_matrix.py:33-40: square_distance(...).topk(k) takes the largest)."""
+    X = pad_features(P)
+    B, N, D = X.shape
+    idx = torch.empty((B, N, k), dtype=torch.int32, device=X.device)
+    ws, nbytes = _fused_ws(B, N, X.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=X.device)
+    check(lib.sed_knn_fused_far_f32(B, N, D, P.shape[2], k, ptr(X), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()),
+          "knn_fused_far")
+    if int(flag.item()) != 0:
+        raise RuntimeError("knn_farthest: candidate list overflow (more than ~190 points at the same distance)")
+    return idx
+
+
+def csr_spmm(rowptr, col, val, X):
+    """Y [B,N,c] = M X for B CSR matrices (rowptr [B,N+1] i32, col / val [B,nnz]) -- the HPNet affinity operator."""
+    B, N, c = X.shape
+    Y = torch.empty_like(X)
+    check(lib.sed_csr_spmm_f32(B, N, c, col.shape[1], ptr(rowptr), ptr(col), ptr(val), ptr(X), ptr(Y), stream()), "csr_spmm")
+    return Y
+
+
 def knn_points_normals(x6, k, W=1.0):
     """kNN graph with the xyz*(1+W*normal) metric on x6 [B,6,N] channel-major -> idx [B,N,k] int32
     (src/PointNet.py:90-137)."""

@@ -4,8 +4,15 @@
 SURVEY.md section 8 row a20 / f-1: this stage is on by default in the reference script
 (generate_predictions_aug.py:58, :371-377) but is not part of the north-star path. The entropy weights -- 83 % of the
 stage's time as torch ops (two chunked N x N x K passes each) -- run as fused HIP kernels (pair_entropy.hip); the
-affinity construction and torch.lobpcg are a torch-on-ROCm restatement that keeps the reference's quirks so that the
-stage can be switched on (`generate_predictions.py --hpnet`). Quirks kept on purpose:
+affinity construction and torch.lobpcg exist as a dense torch-on-ROCm restatement (construction_affinity_matrix_normal,
+kept for the surface and for parity tests), but hpnet_process itself now goes through a SPARSE OPERATOR (round 2): the
+dense N x N matrix (400 MB per cloud) is never built. The farthest-50 graph comes from the streaming kNN kernels
+(knn_fused.hip on negated distances), the matrix the eigen-solver sees,
+    A_sym = 1/2 (S + S^T) + 1e-12 d d^T,   S_ij = (s_ij - 1e-12) d_i d_j on the 50-neighbour pattern,  d = rowsum^-1/2,
+is applied as a CSR product (hpnet_sparse.hip) plus a rank-one term, and the 12 leading eigenvectors come from a
+batched LOBPCG (block [X, R, P], Rayleigh-Ritz on 36 x 36 problems, the reference's 10 iterations from a random start)
+that treats all clouds of the batch at once. Parity of the spectral block is statistical, as for torch.lobpcg itself.
+Quirks kept on purpose:
   * knn_idx takes topk *largest* squared distances: the "50 neighbours" are the 50 FARTHEST points (:35-39);
   * the affinity matrix is dense with 1e-12 background, so the mask in the symmetrisation is all ones (:73-90);
   * compute_entropy covers only the first ITER * CHUNK = 5 * CHUNK points but divides by N^2 (:105, :119-152);
@@ -53,6 +60,129 @@ def construction_affinity_matrix_normal(inputs_xyz, N_gt, sigma=0.1, knn=50):
     return (A + A.permute(0, 2, 1)) / (mask + mask.permute(0, 2, 1)).clamp(1, 2)
 
 
+def sparse_affinity(inputs_xyz, N_gt, sigma=0.1, knn=50):
+    """The matrix of construction_affinity_matrix_normal (:42-92) without the N x N tensor: CSR of
+    M = 1/2 (S + S^T), S_ij = (s_ij - 1e-12) d_i d_j on the farthest-`knn` pattern, and d [B,N] = rowsum^-1/2 with the
+    reference's 1e-12 background counted in the row sums; A_sym = M + 1e-12 d d^T.
+    -> (rowptr [B,N+1] i32, col [B,2 knn N] i32, val [B,2 knn N] f32, d [B,N] f32)."""
+    from sednet_hip import ops
+    B, N, _ = N_gt.shape
+    nn = ops.knn_farthest(inputs_xyz.contiguous().float(), knn).long()                       # [B,N,k]
+    n_sub = torch.gather(N_gt, 1, nn.reshape(B, N * knn, 1).expand(B, N * knn, 3)).view(B, N, knn, 3)
+    dst = torch.acos((N_gt.unsqueeze(2) * n_sub).sum(-1).clamp(-0.99, 0.99))                # :70
+    s = torch.exp(-dst ** 2 / (2 * sigma * sigma))                                           # [B,N,k]
+    s_eff = torch.where(s == 0, torch.full_like(s, 1e-12), s)                                # zeros -> background (:77-80)
+    rowsum = s_eff.sum(-1) + (N - knn) * 1e-12
+    d = 1.0 / rowsum.sqrt()
+    rows = torch.arange(N, device=nn.device).view(1, N, 1).expand(B, N, knn)
+    v = 0.5 * (s_eff - 1e-12) * d.unsqueeze(-1) * torch.gather(d, 1, nn.reshape(B, -1)).view(B, N, knn)
+    r_all = torch.cat([rows.reshape(B, -1), nn.reshape(B, -1)], 1)                           # forward + transposed entries
+    c_all = torch.cat([nn.reshape(B, -1), rows.reshape(B, -1)], 1)
+    v_all = torch.cat([v.reshape(B, -1), v.reshape(B, -1)], 1)
+    order = torch.sort(r_all * N + c_all, dim=1, stable=True)[1]                             # by (row, col): fixed order
+    r_s = torch.gather(r_all, 1, order)
+    rowptr = torch.zeros(B, N + 1, dtype=torch.int64, device=nn.device)
+    rowptr[:, 1:] = torch.cumsum(torch.zeros(B, N, dtype=torch.int64, device=nn.device).scatter_add_(
+        1, r_s, torch.ones_like(r_s)), 1)
+    return (rowptr.int().contiguous(), torch.gather(c_all, 1, order).int().contiguous(),
+            torch.gather(v_all, 1, order).float().contiguous(), d.float().contiguous())
+
+
+def affinity_apply(op, X):
+    """A_sym X for X [B,N,c] (c in {12, 24, 36}) with op = sparse_affinity(...)."""
+    from sednet_hip import ops
+    rowptr, col, val, d = op
+    Y = ops.csr_spmm(rowptr, col, val, X.contiguous())
+    return Y + 1e-12 * d.unsqueeze(-1) * (d.unsqueeze(1) @ X)                                 # rank-one background
+
+
+HOST_RITZ_MAX_BATCH = 64     # up to this many clouds the 36 x 36 Ritz problems are solved on the host (LAPACK: ~30 us each;
+                             # rocSOLVER's eigh costs ~1 ms per call on the device, 80 % of the stage at one cloud per call)
+
+
+def _small_sym_eig(G, H, k):
+    """Ritz step on small matrices (any device): G = S^T S, H = S^T A S [B,m,m] float64 -> coefficients [B,m,k] with
+    C^T G C = I and the k largest Ritz values. Cholesky whitening; if [X, R, P] is numerically dependent (Cholesky
+    breaks down) the eigen-decomposition of G with a cut-off is used instead."""
+    m = G.shape[1]
+    eye = torch.eye(m, dtype=G.dtype, device=G.device)
+    L, info = torch.linalg.cholesky_ex(G)
+    dl = L.diagonal(dim1=1, dim2=2).abs()
+    if int(info.abs().max()) == 0 and bool(torch.isfinite(L).all()) and bool((dl.amin(1) >= 1e-5 * dl.amax(1)).all()):
+        Li = torch.linalg.solve_triangular(L, eye.expand_as(G), upper=False)        # L^-1
+        th, V = torch.linalg.eigh(Li @ H @ Li.transpose(1, 2))
+        Wh = Li.transpose(1, 2)
+    else:
+        w, U = torch.linalg.eigh(G)
+        keep = (w > 1e-10 * w[:, -1:]).to(G.dtype)
+        Wh = U * (keep / w.clamp_min(1e-300).sqrt()).unsqueeze(1)
+        th, V = torch.linalg.eigh(Wh.transpose(1, 2) @ H @ Wh)                      # dropped directions: eigenvalue 0
+    top = torch.argsort(th, dim=1, descending=True)[:, :k]
+    C = torch.gather(Wh @ V, 2, top.unsqueeze(1).expand(-1, m, -1))
+    return C, torch.gather(th, 1, top)
+
+
+def _small_sym_eig_host(G, H, k):
+    """_small_sym_eig on the host with numpy / LAPACK (no thread-pool start-up per 36 x 36 product)."""
+    Cs, ths = [], []
+    for g, h in zip(G, H):
+        m = g.shape[0]
+        try:
+            L = np.linalg.cholesky(g)
+            dl = np.abs(np.diag(L))
+            if dl.min() < 1e-5 * dl.max():                   # [X, R, P] numerically dependent: whitening by Cholesky
+                raise np.linalg.LinAlgError                  # would amplify rounding; use the cut-off route
+            Wh = np.linalg.inv(L).T
+        except np.linalg.LinAlgError:
+            w, U = np.linalg.eigh(g)
+            keep = w > 1e-10 * w[-1]
+            Wh = U * np.where(keep, 1.0 / np.sqrt(np.maximum(w, 1e-300)), 0.0)[None, :]
+        th, V = np.linalg.eigh(Wh.T @ h @ Wh)
+        top = np.argsort(-th)[:k]
+        Cs.append(Wh @ V[:, top])
+        ths.append(th[top])
+    return np.stack(Cs), np.stack(ths)
+
+
+def _rayleigh_ritz(S, AS, k):
+    """largest-k Ritz pairs of A in span(S): S, AS [B,N,m] -> coefficients [B,m,k] (S-orthonormal), values [B,k]."""
+    G = (S.transpose(1, 2) @ S).double()
+    H = (S.transpose(1, 2) @ AS).double()
+    H = 0.5 * (H + H.transpose(1, 2))
+    if S.shape[0] <= HOST_RITZ_MAX_BATCH:
+        C, th = _small_sym_eig_host(G.cpu().numpy(), H.cpu().numpy(), k)   # one small D->H / H->D round trip per iteration
+        return torch.from_numpy(C).float().to(S.device), torch.from_numpy(th).float().to(S.device)
+    C, th = _small_sym_eig(G, H, k)
+    return C.float(), th.float()
+
+
+def lobpcg_sparse(op, k=12, niter=10, X0=None):
+    """k largest eigenpairs of A_sym by LOBPCG (Knyazev 2001: block [X, R, P], no preconditioner), all clouds of the
+    batch at once; the counterpart of torch.lobpcg(A, k=12, niter=10) at smooth_normal_matrix.py:198. Random normal
+    start from torch's global generator on the device (seed with torch.manual_seed for reproducibility).
+    -> (eigenvalues [B,k], eigenvectors [B,N,k])."""
+    d = op[3]
+    B, N = d.shape
+    X = torch.randn(B, N, k, device=d.device) if X0 is None else X0.clone()
+    AX = affinity_apply(op, X)
+    C, lam = _rayleigh_ritz(X, AX, k)                                    # also orthonormalises the random block
+    X, AX = X @ C, AX @ C
+    P = AP = None
+    for _ in range(niter):
+        R = AX - X * lam.unsqueeze(1)
+        R = R - X @ (X.transpose(1, 2) @ R)
+        R = R / R.norm(dim=1, keepdim=True).clamp_min(1e-30)
+        AR = affinity_apply(op, R)
+        S = torch.cat([X, R] if P is None else [X, R, P], 2)
+        AS = torch.cat([AX, AR] if P is None else [AX, AR, AP], 2)
+        C, lam = _rayleigh_ritz(S, AS, k)
+        Cp = C.clone()
+        Cp[:, :k] = 0                                                    # P = the part of the new X outside the old X
+        P, AP = S @ Cp, AS @ Cp
+        X, AX = S @ C, AS @ C
+    return lam, X
+
+
 def compute_entropy(features, CHUNK=2000):
     """:95-153. features [1,N,K] on the device -> scalar tensor. Same coverage (first ITER*CHUNK points), same N^2
     divisor; the per-dimension interval max(f_i - f_j) - min(f_i - f_j) over that block is 2 (max f - min f) in closed
@@ -73,22 +203,34 @@ def compute_entropy(features, CHUNK=2000):
 
 
 def hpnet_process(affinity_feat, inputs_xyz, normals, id=None, types=None, edges=None, normal_smooth_w=0.5, CHUNK=2000,
-                  gpu="cuda:0", drop_rest_idx=None, cache_dir=None):
+                  gpu="cuda:0", drop_rest_idx=None, cache_dir=None, dense=False):
     """:157-233. affinity_feat [B,N,K] (not normalised), inputs_xyz / normals [B,N,3] -> [B,N,K+12(+8)].
-    The reference handles one cloud per call (compute_entropy asserts B == 1); batches are looped here."""
+    The reference handles one cloud per call (compute_entropy asserts B == 1); here the spectral block of all clouds comes
+    from one batched sparse LOBPCG, the entropies are per cloud. dense=True takes the reference's route instead (dense
+    N x N affinity + torch.lobpcg, one cloud at a time)."""
     outs = []
+    edge_topk, normal_sigma, edge_knn = 12, 0.1, 50
+    V = None
+    if not dense and (cache_dir is None or id is None):
+        V = lobpcg_sparse(sparse_affinity(inputs_xyz, normals, sigma=normal_sigma, knn=edge_knn), k=edge_topk, niter=10)[1]
     for b in range(affinity_feat.shape[0]):
         feat = affinity_feat[b:b + 1]
         weight_ent = [1.7 - float(compute_entropy(feat, CHUNK=CHUNK))]
         specs = [feat]
-        edge_topk, normal_sigma, edge_knn = 12, 0.1, 50
         fn = None if (cache_dir is None or id is None) else os.path.join(cache_dir, f"Us_{id}_{b}_{normal_sigma}_{edge_knn}.pt")
         if fn and os.path.exists(fn):
             v, ent = torch.load(fn)
             v = v.to(feat.device)
         else:
-            A = construction_affinity_matrix_normal(inputs_xyz[b:b + 1], normals[b:b + 1], sigma=normal_sigma, knn=edge_knn)
-            v = torch.lobpcg(A, k=edge_topk, niter=10)[1]
+            if V is not None:
+                v = V[b:b + 1]
+            elif dense:
+                A = construction_affinity_matrix_normal(inputs_xyz[b:b + 1], normals[b:b + 1], sigma=normal_sigma,
+                                                        knn=edge_knn)
+                v = torch.lobpcg(A, k=edge_topk, niter=10)[1]
+            else:
+                v = lobpcg_sparse(sparse_affinity(inputs_xyz[b:b + 1], normals[b:b + 1], sigma=normal_sigma,
+                                                  knn=edge_knn), k=edge_topk, niter=10)[1]
             v = v / (torch.norm(v, dim=-1, keepdim=True) + 1e-16)
             ent = compute_entropy(v, CHUNK=CHUNK)
             if fn:

@@ -60,3 +60,56 @@ def test_entropy_needs_device_tensors(T):
     from src import smooth_normal_matrix as snm
     with pytest.raises(RuntimeError):
         snm.compute_entropy(T.zeros(1, 64, 8))
+
+
+def test_sparse_operator_equals_the_dense_matrix(T, golden):
+    """The CSR + rank-one operator (hpnet_sparse.hip, no N x N tensor) applies the same matrix as the dense
+    construction (smooth_normal_matrix.py:42-92): rows of the dense matrix against the operator applied to unit vectors,
+    A X against the dense product for a random block; the farthest-50 graph equals torch.topk up to ties."""
+    from src import smooth_normal_matrix as snm
+    from sednet_hip import ops
+    g = golden("f_hpnet")
+    P, Nn = (T.from_numpy(a).cuda() for a in (g["p"][None], g["n"][None]))
+    N = P.shape[1]
+    nn = ops.knn_farthest(P, 50).long()
+    d2 = snm.square_distance(P, P)[0]
+    kth = d2.topk(50, dim=-1)[0][:, -1:]                                  # 50th largest distance per row
+    picked = T.gather(d2, 1, nn[0])
+    assert bool((picked >= kth - 1e-5 * kth.abs()).all())                 # every pick is among the 50 farthest (ties aside)
+    assert bool((picked[:, :-1] >= picked[:, 1:] - 1e-6).all())           # farthest first
+    A = snm.construction_affinity_matrix_normal(P, Nn, sigma=0.1, knn=50)[0]
+    op = snm.sparse_affinity(P, Nn, sigma=0.1, knn=50)
+    X = T.randn(1, N, 12, generator=T.Generator().manual_seed(1)).cuda()
+    got = snm.affinity_apply(op, X)[0]
+    ref = A.double() @ X[0].double()
+    # the two graphs may differ in a few tied 50th neighbours: compare up to a small fraction of rows
+    err = (got.double() - ref).abs().max(1)[0] / ref.abs().max()
+    assert float((err < 1e-4).float().mean()) > 0.9, float((err < 1e-4).float().mean())
+    # batch of two clouds = the two single-cloud operators
+    P2, N2 = T.cat([P, P.flip(1)]), T.cat([Nn, Nn.flip(1)])
+    op2 = snm.sparse_affinity(P2, N2)
+    X2 = T.cat([X, X.flip(1)])
+    got2 = snm.affinity_apply(op2, X2)
+    np.testing.assert_allclose(got2[0].cpu().numpy(), got.cpu().numpy(), atol=1e-6)
+    same = np.isclose(got2[1].flip(0).cpu().numpy(), got.cpu().numpy(), atol=1e-5).all(1)
+    assert same.mean() > 0.98                      # the flipped cloud breaks exact distance ties by the other index
+
+
+def test_sparse_lobpcg_finds_the_leading_eigenvectors(T, golden):
+    """lobpcg_sparse (batched, 10 iterations from a random start like torch.lobpcg at smooth_normal_matrix.py:198): the
+    Ritz values approach the dense matrix's leading eigenvalues from below and the leading half of the subspace agrees with
+    the exact eigenvectors; more iterations converge it."""
+    from src import smooth_normal_matrix as snm
+    g = golden("f_hpnet")
+    P, Nn = (T.from_numpy(a).cuda() for a in (g["p"][None], g["n"][None]))
+    A = snm.construction_affinity_matrix_normal(P, Nn, sigma=0.1, knn=50)[0].double()
+    w, U = T.linalg.eigh(A)
+    w, U = w.flip(0)[:12], U.flip(1)[:, :12]
+    op = snm.sparse_affinity(P, Nn)
+    T.manual_seed(7)
+    lam, V = snm.lobpcg_sparse(op, k=12, niter=10)
+    assert bool((lam[0].double() <= w * (1 + 1e-4) + 1e-6).all()), (lam[0], w)          # Ritz values: from below
+    sv = T.linalg.svdvals(T.linalg.qr(V[0].double())[0].T @ U)
+    assert int((sv > 0.75).sum()) >= 6, sv
+    lam60, V60 = snm.lobpcg_sparse(op, k=12, niter=60)
+    np.testing.assert_allclose(lam60[0, :6].cpu().numpy(), w[:6].cpu().numpy(), rtol=2e-3)

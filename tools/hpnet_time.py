@@ -20,6 +20,18 @@ import src.smooth_normal_matrix as snm
 def tm(name, f, *a, **k):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize()
     print(f"  {name}: {(time.perf_counter() - t0) * 1e3:.1f} ms"); return r
+for Bn in (1, 16):
+    Pb, Nb, Fb = (t.expand(Bn, -1, -1).contiguous() for t in (P, Nn, F))
+    for rep in range(2):
+        op = tm(f"[sparse] affinity operator B={Bn}", snm.sparse_affinity, Pb, Nb)
+        tm(f"[sparse] batched lobpcg B={Bn}", snm.lobpcg_sparse, op)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); hpnet_process(Fb, Pb, Nb); torch.cuda.synchronize()
+    print(f"  hpnet_process B={Bn}: {(time.perf_counter() - t0) * 1e3 / Bn:.2f} ms per cloud")
+from torch.profiler import profile, ProfilerActivity
+op = snm.sparse_affinity(P, Nn)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    snm.lobpcg_sparse(op); torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=50))
 tm("entropy(feat 128)", snm.compute_entropy, F)
 tm("knn_idx farthest-50", snm.knn_idx, P, 50)
 A = tm("affinity", snm.construction_affinity_matrix_normal, P, Nn, 0.1, 50)

@@ -178,6 +178,24 @@ size_t sed_pointwise_colext_bytes(int B, int N, int Coutp);
 int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
                           const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
                           int flags, sed_stream_t stream);
+/* ---- training products (BASELINE configs[4]: bf16) ---------------------------------------------
+ * sed_pointwise_fwd_bf16 / sed_edgeconv_fwd_train_bf16: the fp32 entry points' contracts with the products in bf16
+ * (operands rounded to nearest even while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 / fp64 statistics;
+ * tensors stay fp32 in memory). The reference trains in fp32 (train_sed_net.py:233-283). */
+int sed_pointwise_fwd_bf16(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
+                           const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
+                           int flags, sed_stream_t stream);
+int sed_edgeconv_fwd_train_bf16(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
+                                const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel,
+                                float* stats, unsigned char* jsel, void* partials, size_t partials_bytes,
+                                sed_stream_t stream);
+/* C [M,N] = op(A) op(B): A(m,k) = transA ? A[k lda + m] : A[m lda + k], B(k,n) = transB ? B[n ldb + k] : B[k ldb + n];
+ * fp32 in memory, products bf16 (bf16 != 0) or exact fp32 MFMA chains. The two GEMMs of a pointwise layer's backward
+ * (dX = dy W, dW = dy^T X; the reference gets them from torch.autograd, train_sed_net.py:272). Long reductions are
+ * split over sed_gemm_splits(M, N, K) partial products added in fixed order (workspace: splits * M * N floats). */
+int sed_gemm_splits(int M, int N, int K);
+int sed_gemm_f32(int M, int N, int K, const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C,
+                 int ldc, int bf16, void* workspace, size_t workspace_bytes, sed_stream_t stream);
 /* (mean, rstd) per (cloud, group) from the partial sums of sed_pointwise_fwd_f32.  torch.nn.GroupNorm */
 int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps, const void* partials, float* stats,
                         sed_stream_t stream);

@@ -24,7 +24,12 @@ namespace {
 
 // TRAIN additionally records which neighbour slot produced the selected extreme (first one on ties): the backward
 // pass routes the max-over-k gradient there (edgeconv_bwd.hip).
-template <int CH, bool TRAIN>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16 (training, BASELINE configs[4]; CH = 32 only): the difference x_j - x_i is still formed in fp32, then rounded to
+// bf16 (nearest even) like the weights; products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 / fp64 statistics.
+// LDS holds the two weight halves transposed, [64 out channels][64 in channels] bf16 with a 144-byte row stride.
+template <int CH, bool TRAIN, bool BF16 = false>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
 __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restrict__ x, int ldx,
                                                           const int* __restrict__ idx, int k,
                                                           const float* __restrict__ W1t,
@@ -47,12 +52,35 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
     const int cloud = wgid / nbx, bxi = wgid - cloud * nbx;
     const int slab = blockIdx.z, o0 = slab * 64;
+    constexpr int LDWB = C + 8;                  // bf16 image row stride in halves (144 B for C = 64)
+    __bf16* w1b = (__bf16*)smem;                 // [64][LDWB]
+    __bf16* w2b = w1b + 64 * LDWB;
     for (int i = tid; i < C * 64; i += 256) {
         const int c = i >> 6, o = i & 63;
-        w1[i] = W1t[(size_t)c * Cout + o0 + o];
-        w2[i] = W2t[(size_t)c * Cout + o0 + o];
+        if (BF16) {
+            w1b[o * LDWB + c] = (__bf16)W1t[(size_t)c * Cout + o0 + o];
+            w2b[o * LDWB + c] = (__bf16)W2t[(size_t)c * Cout + o0 + o];
+        } else {
+            w1[i] = W1t[(size_t)c * Cout + o0 + o];
+            w2[i] = W2t[(size_t)c * Cout + o0 + o];
+        }
     }
     __syncthreads();
+    // bf16 product of this lane's CH channels (k-step s8 = channels hi * CH + 8 s8 .. + 8) with a transposed weight image
+    auto mma_bf16 = [&](const float (&v)[CH], const __bf16* wb, f32x16 (&acc)[2]) {
+        if constexpr (BF16) {
+#pragma unroll
+            for (int s8 = 0; s8 < CH / 8; ++s8) {
+                bf16x8 a;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = (__bf16)v[8 * s8 + i];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        a, *(const bf16x8*)(wb + (32 * t + li) * LDWB + hi * CH + 8 * s8), acc[t], 0, 0, 0);
+            }
+        }
+    };
 
     const int p0 = bxi * 128 + wave * 32;
     const int p = p0 + li;
@@ -82,10 +110,14 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) base[t][r] = 0.f;
+    if (BF16) {
+        mma_bf16(xc, w2b, base);
+    } else {
 #pragma unroll
-    for (int s = 0; s < CH; ++s)
+        for (int s = 0; s < CH; ++s)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) base[t] = mfma32(xc[s], w2[(hi * CH + s) * 64 + 32 * t + li], base[t]);
+            for (int t = 0; t < 2; ++t) base[t] = mfma32(xc[s], w2[(hi * CH + s) * 64 + 32 * t + li], base[t]);
+    }
 
     float sg[2];
 #pragma unroll
@@ -109,10 +141,14 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
         for (int s = 0; s < CH; ++s) diff[s] = nxt[s] - xc[s];         // feature - x   (PointNet.py:170)
         if (j + 1 < k) load_row(ib[j + 1], nxt);
         f32x16 acc[2] = {base[0], base[1]};
+        if (BF16) {
+            mma_bf16(diff, w1b, acc);
+        } else {
 #pragma unroll
-        for (int s = 0; s < CH; ++s)
+            for (int s = 0; s < CH; ++s)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[t] = mfma32(diff[s], w1[(hi * CH + s) * 64 + 32 * t + li], acc[t]);
+                for (int t = 0; t < 2; ++t) acc[t] = mfma32(diff[s], w1[(hi * CH + s) * 64 + 32 * t + li], acc[t]);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float ps = 0.f, pq = 0.f;
@@ -197,7 +233,7 @@ extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
 // GroupNorm gamma >= 0 else -1. Outputs: ysel [B,N,Cout], stats [B][G][2] = (mean, rstd) over all N*k*(Cout/G).
 static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                         const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
-                        void* partials, size_t partials_bytes, uint8_t* jsel, hipStream_t stream) {
+                        void* partials, size_t partials_bytes, uint8_t* jsel, hipStream_t stream, bool bf16 = false) {
     if (B <= 0 || N <= 0 || k <= 0 || !x || !idx || !W1t || !W2t || !sgn || !ysel || !stats || !partials)
         return SED_EINVAL;
     if (Cout % 64 != 0 || G <= 0 || (Cout / G) % 32 != 0 || ldx < C) return SED_EUNSUPPORTED;
@@ -214,7 +250,9 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
     } else if (C == 64) {
         if (ldx % 4 != 0) return SED_EUNSUPPORTED;
         const size_t sm = 2 * 64 * 64 * sizeof(float) + 16 * sizeof(double);
-        if (jsel)
+        if (jsel && bf16)
+            edgeconv_kernel<32, true, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
+        else if (jsel)
             edgeconv_kernel<32, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
         else
             edgeconv_kernel<32, false><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, nullptr);
@@ -243,4 +281,14 @@ extern "C" int sed_edgeconv_fwd_train_f32(int B, int N, int C, int Cout, int k, 
     if (!jsel || k > 255) return SED_EINVAL;
     return edgeconv_fwd(B, N, C, Cout, k, G, x, ldx, idx, W1t, W2t, sgn, eps, ysel, stats, partials, partials_bytes,
                         jsel, stream);
+}
+
+// Training forward with bf16 products (64-channel layers; the 6-channel input layer -- 0.5 % of the flops -- stays fp32).
+extern "C" int sed_edgeconv_fwd_train_bf16(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
+                                           const int* idx, const float* W1t, const float* W2t, const float* sgn,
+                                           float eps, float* ysel, float* stats, uint8_t* jsel, void* partials,
+                                           size_t partials_bytes, hipStream_t stream) {
+    if (!jsel || k > 255) return SED_EINVAL;
+    return edgeconv_fwd(B, N, C, Cout, k, G, x, ldx, idx, W1t, W2t, sgn, eps, ysel, stats, partials, partials_bytes,
+                        jsel, stream, true);
 }

@@ -20,7 +20,14 @@ namespace {
 
 enum { F_RELU = 1, F_STORE = 2, F_STATS = 4, F_COLEXT = 8 };
 
-template <int TN>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// BF16 (training, BASELINE configs[4]): both operands are rounded to bf16 (round to nearest even) while they are staged
+// into LDS and the products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias, statistics (fp64 partials) and
+// the stored output stay fp32. LDS then holds A as [128 points][32 k] bf16 (row stride 80 B) and B TRANSPOSED as
+// [BN channels][32 k] bf16 (row stride 80 B), so that every MFMA operand is one ds_read_b128.
+template <int TN, bool BF16>
 __global__ __launch_bounds__(256, 2) void pointwise_kernel(const float* __restrict__ X, int ldx, int K,
                                                            const float* __restrict__ Wt, int ldw,
                                                            const float* __restrict__ bias,
@@ -56,16 +63,31 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const float* __restri
             sb[u] = *(const f32x4*)(Wt + (size_t)(ch * 32 + row) * ldw + o0 + 4 * c4);
         }
     };
+    // bf16 images inside the same LDS regions: A [buf][128][40 halves], B^T [buf][BN][40 halves]
+    __bf16* Ab = (__bf16*)As;
+    __bf16* Bb = (__bf16*)Bs;
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, row = i >> 3, c4 = i & 7;
-            *(f32x4*)(As + (buf * 128 + row) * LDA + 4 * c4) = sa[u];
+            if (BF16) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)sa[u][e];
+                *(bf16x4*)(Ab + (buf * 128 + row) * 40 + 4 * c4) = h;
+            } else {
+                *(f32x4*)(As + (buf * 128 + row) * LDA + 4 * c4) = sa[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             const int i = tid + 256 * u, row = i / (BN / 4), c4 = i % (BN / 4);
-            *(f32x4*)(Bs + (buf * 32 + row) * BN + 4 * c4) = sb[u];
+            if (BF16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bb[(buf * BN + 4 * c4 + e) * 40 + row] = (__bf16)sb[u][e];   // transpose
+            } else {
+                *(f32x4*)(Bs + (buf * 32 + row) * BN + 4 * c4) = sb[u];
+            }
         }
     };
 
@@ -81,15 +103,28 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const float* __restri
     int cur = 0;
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ch + 1 < nchunk) stage_load(ch + 1);
-        const float* a = As + (cur * 128 + wave * 32 + li) * LDA + hi * 16;
-        const float* b = Bs + (cur * 32 + hi * 16) * BN + li;
+        if (BF16) {
+            const __bf16* a = Ab + (cur * 128 + wave * 32 + li) * 40 + hi * 8;
+            const __bf16* b = Bb + (cur * BN + li) * 40 + hi * 8;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const f32x4 av = *(const f32x4*)(a + 4 * s4);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 av = *(const bf16x8*)(a + 16 * s2);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int t = 0; t < TN; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(b + 32 * t * 40 + 16 * s2), acc[t],
+                                                                     0, 0, 0);
+            }
+        } else {
+            const float* a = As + (cur * 128 + wave * 32 + li) * LDA + hi * 16;
+            const float* b = Bs + (cur * 32 + hi * 16) * BN + li;
 #pragma unroll
-                for (int t = 0; t < TN; ++t) acc[t] = mfma32(av[c], b[(4 * s4 + c) * BN + 32 * t], acc[t]);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const f32x4 av = *(const f32x4*)(a + 4 * s4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = mfma32(av[c], b[(4 * s4 + c) * BN + 32 * t], acc[t]);
+            }
         }
         if (ch + 1 < nchunk) stage_store(cur ^ 1);
         __syncthreads();
@@ -257,9 +292,27 @@ extern "C" size_t sed_pointwise_colext_bytes(int B, int N, int Coutp) {
 // flags: 1 ReLU, 2 store Y, 4 statistics partials, 8 column extrema.
 // Wt [K][Coutp] (K multiple of 32, Coutp multiple of 64, zero padded), bias [Coutp] or NULL,
 // cbias [B][Coutp] or NULL, Y [B,N,ldy] (first Cout columns written).
+static int pointwise_fwd(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
+                         const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
+                         int flags, bool bf16, hipStream_t stream);
+
 extern "C" int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
                                      const float* Wt, const float* bias, const float* cbias, float* Y, int ldy,
                                      void* partials, void* colext, int flags, hipStream_t stream) {
+    return pointwise_fwd(B, N, K, Coutp, Cout, X, ldx, Wt, bias, cbias, Y, ldy, partials, colext, flags, false, stream);
+}
+
+// Same contract, products in bf16 (operands rounded to nearest even while staged, fp32 accumulate / epilogue): the
+// training path of BASELINE configs[4]. Inputs and outputs stay fp32 in memory.
+extern "C" int sed_pointwise_fwd_bf16(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
+                                      const float* Wt, const float* bias, const float* cbias, float* Y, int ldy,
+                                      void* partials, void* colext, int flags, hipStream_t stream) {
+    return pointwise_fwd(B, N, K, Coutp, Cout, X, ldx, Wt, bias, cbias, Y, ldy, partials, colext, flags, true, stream);
+}
+
+static int pointwise_fwd(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
+                         const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
+                         int flags, bool bf16, hipStream_t stream) {
     if (B <= 0 || N <= 0 || !X || !Wt) return SED_EINVAL;
     if (K % 32 != 0 || Coutp % 64 != 0 || ldx % 4 != 0 || ldx < K || Cout > Coutp) return SED_EUNSUPPORTED;
     if ((flags & F_STORE) && (!Y || ldy < Cout)) return SED_EINVAL;
@@ -269,18 +322,29 @@ extern "C" int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, c
     if (Coutp % 128 == 0) {
         static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in once per process
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)pointwise_kernel<4>,
+            hipError_t e = hipFuncSetAttribute((const void*)pointwise_kernel<4, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)pointwise_kernel<4, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
         const size_t sm = (2 * 128 * 36 + 2 * 32 * 128) * sizeof(float) + 4 * 4 * 2 * sizeof(double) + 4 * 128 * 2 * sizeof(float);
-        pointwise_kernel<4><<<dim3(nblk, B, Coutp / 128), 256, sm, stream>>>(
-            X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+        if (bf16)
+            pointwise_kernel<4, true><<<dim3(nblk, B, Coutp / 128), 256, sm, stream>>>(
+                X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+        else
+            pointwise_kernel<4, false><<<dim3(nblk, B, Coutp / 128), 256, sm, stream>>>(
+                X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
     } else {
         const size_t sm = (2 * 128 * 36 + 2 * 32 * 64) * sizeof(float) + 4 * 2 * 2 * sizeof(double) + 4 * 64 * 2 * sizeof(float);
-        pointwise_kernel<2><<<dim3(nblk, B, Coutp / 64), 256, sm, stream>>>(
-            X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+        if (bf16)
+            pointwise_kernel<2, true><<<dim3(nblk, B, Coutp / 64), 256, sm, stream>>>(
+                X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+        else
+            pointwise_kernel<2, false><<<dim3(nblk, B, Coutp / 64), 256, sm, stream>>>(
+                X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
     }
     SED_LAUNCH_CHECK();
     return SED_OK;

@@ -62,6 +62,11 @@ SIGNATURES = {
     "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_colext_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_pointwise_fwd_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_edgeconv_fwd_train_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,
+                                            P, P, P, c_size_t, P]),
+    "sed_gemm_splits": (c_int, [c_int, c_int, c_int]),
+    "sed_gemm_f32": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),
     "sed_gn_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_double, c_float, P, P, P]),
     "sed_gn_apply_f32": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_float, c_float, P, c_int,
                                  P, c_int, P]),

@@ -5,7 +5,10 @@ The reference differentiates Conv -> GroupNorm -> activation [-> max over k] wit
 Here the forward is the fused HIP kernel of the inference path (plus the selected-slot record), the backward is
 edgeconv_bwd.hip: GroupNorm's backward reduced to  dy = S [j == j*] + alpha_g + kappa_g y  and, for EdgeConv, two
 kernels that recompute y tile by tile instead of storing it. The two GEMMs of a pointwise layer's backward
-(dX = dy W, dW = dy^T X) are plain library GEMMs (torch.matmul -> rocBLAS).
+(dX = dy W, dW = dy^T X) run on the repo's own MFMA GEMM (gemm.hip; round 1 called rocBLAS through torch.matmul).
+ops.TRAIN_BF16 = True switches the forward products of the 64-channel EdgeConv layers and of every pointwise layer, and
+both backward GEMMs, to bf16 (operands rounded while staged, fp32 accumulate; weights, activations in memory, GroupNorm
+statistics and the EdgeConv backward stay fp32) -- BASELINE configs[4].
 
 Activations are point-major [B,N,C]; indices are not differentiated (topk indices carry no gradient in the reference
 either).
@@ -37,7 +40,7 @@ class EdgeConvGN(torch.autograd.Function):
         b = beta.detach().float().contiguous()
         sgn = torch.where(g >= 0, 1.0, -1.0).float().contiguous()
         xd = x.detach().contiguous()
-        ysel, stats, jsel = ops.edgeconv_train(xd, C, idx, W1t, W2t, sgn, G, eps)
+        ysel, stats, jsel = ops.edgeconv_train(xd, C, idx, W1t, W2t, sgn, G, eps, bf16=ops.TRAIN_BF16)
         out = torch.empty_like(ysel)
         ops.gn_apply(ysel, ysel.shape[2], G, stats, g, b, ops.ACT_LEAKY, out, slope=slope)
         ctx.save_for_backward(xd, idx, W1t, W2t, g, b, ysel, stats, jsel)
@@ -77,7 +80,7 @@ class ConvGNAct(torch.autograd.Function):
             bp[:Cout] = bias.detach().float()
         cb = cbias.detach().float().contiguous() if cbias is not None else None
         Y, stats, _ = ops.pointwise(Xd, _wt_pad(W), Cout, bias=bp, cbias=cb, flags=ops.F_STORE | ops.F_STATS, G=G,
-                                    eps=eps)
+                                    eps=eps, bf16=ops.TRAIN_BF16)
         out = torch.empty((Y.shape[0], Y.shape[1], Cout), dtype=torch.float32, device=Y.device)
         ops.gn_apply(Y, Cout, G, stats, g, b, act, out)
         ctx.save_for_backward(Xd, W, g, b, Y, stats)
@@ -92,8 +95,10 @@ class ConvGNAct(torch.autograd.Function):
         S, dgamma, dbeta, ak = ops.gn_bwd_reduce(dout.contiguous(), Y, Cout, G, float(Cout // G) * N, stats, g, b, act)
         dy = ops.gn_bwd_apply(S, Y, Cout, G, ak)
         K = W.shape[1]
-        dX = torch.matmul(dy, W) if ctx.needs_input_grad[0] else None
-        dW = torch.matmul(dy.reshape(B * N, Cout).t(), Xd[:, :, :K].reshape(B * N, K)).reshape(wshape)
+        dy2 = dy.reshape(B * N, Cout)
+        dX = ops.gemm(dy2, W).reshape(B, N, K) if ctx.needs_input_grad[0] else None            # dX = dy W
+        X2 = Xd.as_strided((B * N, K), (Xd.stride(1), 1), Xd.storage_offset())               # [P, K] view of the saved input
+        dW = ops.gemm(dy2, X2, transA=True).reshape(wshape)                                  # dW = dy^T X
         dcb = dy.sum(1) if has_cbias else None
         dbias = (dcb.sum(0) if has_cbias else dy.sum((0, 1))) if has_bias else None
         return dX, dW, dbias, dcb, dgamma, dbeta, None, None, None

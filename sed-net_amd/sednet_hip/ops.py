@@ -313,8 +313,9 @@ def edgeconv(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
     return ysel, stats
 
 
-def edgeconv_train(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
-    """edgeconv() + jsel [B,N,Cout] u8 (slot selected by the max over k) for the backward pass."""
+def edgeconv_train(x, C, idx, W1t, W2t, sgn, G, eps=1e-5, bf16=False):
+    """edgeconv() + jsel [B,N,Cout] u8 (slot selected by the max over k) for the backward pass. bf16: products of the
+    64-channel layers in bf16 (the 6-channel input layer stays fp32)."""
     B, N, ldx = x.shape
     k = idx.shape[2]
     Cout = W1t.shape[1]
@@ -323,9 +324,9 @@ def edgeconv_train(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
     stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
     nb = lib.sed_edgeconv_partials_bytes(B, N, Cout)
     part = _bytes(nb, x.device)
-    check(lib.sed_edgeconv_fwd_train_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(sgn),
-                                         float(eps), ptr(ysel), ptr(stats), ptr(jsel), ptr(part), nb, stream()),
-          "edgeconv_fwd_train")
+    fwd = lib.sed_edgeconv_fwd_train_bf16 if (bf16 and C == 64) else lib.sed_edgeconv_fwd_train_f32
+    check(fwd(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(sgn), float(eps), ptr(ysel), ptr(stats),
+              ptr(jsel), ptr(part), nb, stream()), "edgeconv_fwd_train")
     return ysel, stats, jsel
 
 
@@ -386,9 +387,31 @@ def _vptr(t):
     return _lib.c_void_p(t.data_ptr())
 
 
-def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5):
-    """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp].
-    Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
+TRAIN_BF16 = False      # training products in bf16 (operands rounded while staged, fp32 accumulate): BASELINE configs[4]
+
+
+def gemm(A, B, transA=False, transB=False, bf16=None):
+    """C [M,N] = op(A) op(B) on the repo's own MFMA GEMM (gemm.hip): the backward products of the pointwise layers.
+    A: [M,K] (or [K,M] with transA), B: [K,N] (or [N,K] with transB); 2-D fp32, unit inner stride, row stride % 4 == 0."""
+    bf16 = TRAIN_BF16 if bf16 is None else bf16
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    assert (B.shape[1] if transB else B.shape[0]) == K and A.stride(1) == 1 and B.stride(1) == 1
+    assert A.is_cuda and B.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32
+    p2 = lambda t: _lib.c_void_p(t.data_ptr())                     # 2-D row-strided views
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ns = lib.sed_gemm_splits(M, N, K)
+    ws = torch.empty((ns * M * N,), dtype=torch.float32, device=A.device) if ns > 1 else None
+    check(lib.sed_gemm_f32(M, N, K, p2(A), A.stride(0), int(transA), p2(B), B.stride(0), int(transB), ptr(C), N,
+                           int(bool(bf16)), ptr(ws) if ws is not None else None, ns * M * N * 4 if ns > 1 else 0, stream()),
+          "gemm")
+    return C
+
+
+def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False):
+    """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp]. bf16: products in bf16
+    (training). Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
     B, N = X.shape[0], X.shape[1]
     K, Coutp = Wt.shape
     dev = X.device
@@ -396,12 +419,12 @@ def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, 
         out = torch.empty((B, N, Coutp), dtype=torch.float32, device=dev)[:, :, :Cout]
     part = _bytes(lib.sed_pointwise_partials_bytes(B, N, Coutp), dev) if flags & F_STATS else None
     colext = _bytes(lib.sed_pointwise_colext_bytes(B, N, Coutp), dev) if flags & F_COLEXT else None
-    check(lib.sed_pointwise_fwd_f32(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), ptr(Wt),
-                                    ptr(bias) if bias is not None else None,
-                                    ptr(cbias) if cbias is not None else None,
-                                    _vptr(out) if out is not None else None, out.stride(1) if out is not None else 0,
-                                    ptr(part) if part is not None else None,
-                                    ptr(colext) if colext is not None else None, flags, stream()), "pointwise_fwd")
+    fwd = lib.sed_pointwise_fwd_bf16 if bf16 else lib.sed_pointwise_fwd_f32
+    check(fwd(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), ptr(Wt),
+              ptr(bias) if bias is not None else None, ptr(cbias) if cbias is not None else None,
+              _vptr(out) if out is not None else None, out.stride(1) if out is not None else 0,
+              ptr(part) if part is not None else None, ptr(colext) if colext is not None else None, flags, stream()),
+          "pointwise_fwd")
     stats = None
     if flags & F_STATS:
         stats = torch.empty((B, G, 2), dtype=torch.float32, device=dev)

@@ -195,3 +195,107 @@ def test_training_steps_reduce_the_loss(T):
         hist.append(train_step(m, opt, batch, smoothing=0.025)["loss"])
     assert np.isfinite(hist).all()
     assert hist[-1] < hist[0], hist
+
+
+def _bf16_round(T, a):
+    return a.to(T.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,N,K,tA,tB", [(300, 256, 512, False, False), (256, 512, 40000, True, False),
+                                         (130, 70, 1000, False, True), (64, 128, 33, True, True)])
+def test_own_gemm_matches_torch(T, M, N, K, tA, tB):
+    """gemm.hip (the backward products of the pointwise layers; round 1 called rocBLAS): fp32 mode against a float64
+    product, bf16 mode against the float64 product of the bf16-rounded operands (the only difference then is the fp32
+    accumulation order); split-K (the 40 000-row reduction) is deterministic."""
+    from sednet_hip import ops
+    g = T.Generator().manual_seed(M + N + K)
+    A = T.randn((K, M) if tA else (M, K), generator=g).cuda()
+    B = T.randn((N, K) if tB else (K, N), generator=g).cuda()
+    if K % 4 or (M % 4 and tA) or (N % 4 and not tB):                   # row strides must be multiples of 4 floats
+        A = T.nn.functional.pad(A, (0, (-A.shape[1]) % 4))[:, :A.shape[1]]
+        B = T.nn.functional.pad(B, (0, (-B.shape[1]) % 4))[:, :B.shape[1]]
+    opA = (lambda t: t.t()) if tA else (lambda t: t)
+    opB = (lambda t: t.t()) if tB else (lambda t: t)
+    ref = (opA(A).double() @ opB(B).double()).cpu().numpy()
+    got = ops.gemm(A, B, tA, tB, bf16=False)
+    close(got.cpu().numpy(), ref, 3e-6 * np.sqrt(K), "fp32")
+    assert T.equal(got, ops.gemm(A, B, tA, tB, bf16=False))               # fixed-order split-K
+    refb = (opA(_bf16_round(T, A)).double() @ opB(_bf16_round(T, B)).double()).cpu().numpy()
+    close(ops.gemm(A, B, tA, tB, bf16=True).cpu().numpy(), refb, 3e-6 * np.sqrt(K), "bf16")
+
+
+def test_bf16_layers_equal_fp32_layers_on_rounded_operands(T):
+    """bf16 products = fp32 products of the bf16-rounded operands (fp32 accumulate): pointwise layer and the 64-channel
+    EdgeConv layer, forward values and all gradients (the EdgeConv backward kernels stay fp32)."""
+    from sednet_hip import autograd as hag, ops
+    rng = np.random.default_rng(0)
+    B, N, K, Cout, G = 2, 300, 256, 128, 4
+    X = T.from_numpy(rng.normal(size=(B, N, K)).astype(np.float32)).cuda()
+    W = T.from_numpy((rng.normal(size=(Cout, K, 1)) / 16).astype(np.float32)).cuda()
+    bias, gamma, beta = (T.from_numpy(rng.normal(size=Cout).astype(np.float32)).cuda() for _ in range(3))
+    cot = T.from_numpy(rng.normal(size=(B, N, Cout)).astype(np.float32)).cuda()
+
+    def run(Xin, Win, bf16):
+        ops.TRAIN_BF16 = bf16
+        try:
+            Xt, Wt = Xin.clone().requires_grad_(True), Win.clone().requires_grad_(True)
+            out = hag.ConvGNAct.apply(Xt, Wt, bias, None, gamma, beta, G, 1e-5, 1)
+            (out * cot).sum().backward()
+            return out.detach(), Xt.grad, Wt.grad
+        finally:
+            ops.TRAIN_BF16 = False
+    ob, dXb, dWb = run(X, W, True)
+    of, _, _ = run(_bf16_round(T, X), _bf16_round(T, W), False)
+    close(ob.cpu().numpy(), of.cpu().numpy(), 2e-5, "pointwise forward")
+    o32, dX32, dW32 = run(X, W, False)
+    close(ob.cpu().numpy(), o32.cpu().numpy(), 2e-2, "pointwise bf16 vs fp32")
+    _mostly_close(dXb.cpu().numpy(), dX32.cpu().numpy(), 3e-2, 0.99)       # a ReLU unit near 0 may switch after rounding
+    close(dWb.cpu().numpy(), dW32.cpu().numpy(), 3e-2, "dW bf16 vs fp32")
+    # EdgeConv, C = 64
+    C, Co, k = 64, 128, 12
+    x = T.from_numpy(rng.normal(size=(B, N, C)).astype(np.float32)).cuda()
+    We = T.from_numpy((rng.normal(size=(Co, 2 * C, 1, 1)) / 11).astype(np.float32)).cuda()
+    ge, be = (T.from_numpy(rng.normal(size=Co).astype(np.float32)).cuda() for _ in range(2))
+    idx = T.from_numpy(np.stack([np.stack([rng.permutation(N)[:k] for _ in range(N)]) for _ in range(B)]).astype(np.int32)).cuda()
+    cote = T.from_numpy(rng.normal(size=(B, N, Co)).astype(np.float32)).cuda()
+
+    def run_e(bf16):
+        ops.TRAIN_BF16 = bf16
+        try:
+            xt, wt = x.clone().requires_grad_(True), We.clone().requires_grad_(True)
+            out = hag.EdgeConvGN.apply(xt, idx, wt, ge, be, C, 2, 1e-5, 0.2)
+            (out * cote).sum().backward()
+            return out.detach().cpu().numpy(), xt.grad.cpu().numpy(), wt.grad.cpu().numpy()
+        finally:
+            ops.TRAIN_BF16 = False
+    eb, ef = run_e(True), run_e(False)
+    frac = np.mean(np.abs(eb[0] - ef[0]) <= 3e-2 * np.abs(ef[0]).max())
+    assert frac > 0.995, frac                                  # a max over k may pick another neighbour after rounding
+    close(eb[2], ef[2], 5e-2, "EdgeConv dW bf16 vs fp32")
+
+
+def test_bf16_training_tracks_fp32(T):
+    """BASELINE configs[4] in small: 30 AdamW steps on one synthetic batch in fp32 and with bf16 products, same
+    initial weights and the same triplet draws: the two loss curves stay together and both go down."""
+    from sednet_hip import ops, synth
+    from sednet_hip.train import train_step
+    from train_case import train_case
+    x, labels, types, edges, edges_w, _ = train_case(synth, 2048, 2, seed0=500)
+    batch = tuple(T.from_numpy(a).cuda() for a in (x, labels, types, edges, edges_w))
+    curves = {}
+    for bf16 in (False, True):
+        ops.TRAIN_BF16 = bf16
+        try:
+            m = _model(T, 20, 3)
+            opt = T.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
+            hist = []
+            for it in range(30):
+                np.random.seed(5)
+                hist.append(train_step(m, opt, batch, smoothing=0.025)["loss"])
+            curves[bf16] = np.array(hist)
+        finally:
+            ops.TRAIN_BF16 = False
+    f, b = curves[False], curves[True]
+    assert np.isfinite(b).all() and b[-1] < 0.9 * b[0] and f[-1] < 0.9 * f[0], (f, b)
+    assert abs(b[0] - f[0]) < 2e-2 * abs(f[0])                               # same weights: bf16 rounding only
+    assert np.abs(b - f).max() < 0.15 * np.abs(f).max(), (f, b)             # the curves stay together

@@ -20,7 +20,11 @@ from sednet_hip.train import train_step, training_loss  # noqa: E402
 from src.SEDNet import SEDNet  # noqa: E402
 from train_case import train_case  # noqa: E402
 
-B, N, k, steps = (int(a) for a in (sys.argv[1:] + ["4", "10000", "64", "5"][len(sys.argv) - 1:]))
+from sednet_hip import ops  # noqa: E402
+
+argv = [a for a in sys.argv[1:] if a != "--bf16"]
+ops.TRAIN_BF16 = "--bf16" in sys.argv                    # bf16 products (BASELINE configs[4]); default: fp32 like the reference
+B, N, k, steps = (int(a) for a in (argv + ["4", "10000", "64", "5"][len(argv):]))
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 dist = None
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())

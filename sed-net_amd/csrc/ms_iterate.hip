@@ -792,7 +792,9 @@ int ms_chunks(int N) {
     return S < 2 ? 2 : (S > 32 ? 32 : S);
 }
 
-enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3, MS_F16 = 4 };
+enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3, MS_F16 = 4, MS_F16_CHUNKED = 5 };
+
+int ms_f16_chunks(int N);      // ms_iterate_f16.hip
 
 // `have_ws`: a workspace large enough for the key-chunked partials; `have_f16`: one large enough for the split-fp16
 // stage images. The split-fp16 kernel (ms_iterate_f16.hip: 5.3 x less matrix time, fp32-equivalent error) is the
@@ -801,7 +803,15 @@ int ms_plan(int B, int N, int d, bool have_ws, bool have_f16, int forced) {
     const long W = (long)B * ((N + 127) / 128), W4 = (long)B * ((N + 31) / 32);
     const int S = ms_chunks(N);
     if (forced == MS_F16) return (d == 128 && have_f16) ? MS_F16 : MS_BATCHED;
-    if (!forced && d == 128 && have_f16 && (B >= 2 || N < 2560)) return MS_F16;
+    if (forced == MS_F16_CHUNKED) return (d == 128 && have_f16 && ms_f16_chunks(N)) ? MS_F16_CHUNKED : MS_BATCHED;
+    if (!forced && d == 128 && have_f16) {
+        // few clouds: the 256-row workgroups of the split-fp16 kernel leave CUs idle; its key-chunked form fills them
+        // (cost in rounds of 256 workgroups x stages per workgroup, +10 % for the partials)
+        const int Sf = ms_f16_chunks(N);
+        const long Wf = (long)B * ((N + 255) / 256);
+        if (Sf && 1.10 * (double)((Wf * Sf + 255) / 256) / Sf < (double)((Wf + 255) / 256)) return MS_F16_CHUNKED;
+        return MS_F16;
+    }
     if (forced == MS_CHUNKED) return (S && have_ws) ? MS_CHUNKED : MS_BATCHED;
     if (forced == MS_SPLITK && d != 128) return MS_BATCHED;
     if (forced) return forced;
@@ -817,12 +827,24 @@ int g_ms_variant = 0;      // 0 = choose by size, 1 = batched fp32, 2 = split-ke
 }  // namespace
 
 // ms_iterate_f16.hip
+size_t ms_f16_chunked_workspace_bytes(int B, int N);
+int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                          int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
+                                                          hipStream_t),
+                          hipStream_t stream);
 size_t ms_f16_workspace_bytes(int B, int N);
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                   int** flags_out, hipStream_t stream);
 
+static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
+                             hipStream_t stream) {
+    ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, 128);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
 extern "C" int sed_ms_set_variant(int variant) {
-    if (variant < 0 || variant > 4) return SED_EINVAL;
+    if (variant < 0 || variant > 5) return SED_EINVAL;
     g_ms_variant = variant;
     return SED_OK;
 }
@@ -838,6 +860,7 @@ extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
     if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
     const int plan = ms_plan(B, N, d, true, true, g_ms_variant);
     if (plan == MS_F16) return ms_f16_workspace_bytes(B, N);
+    if (plan == MS_F16_CHUNKED) return ms_f16_chunked_workspace_bytes(B, N);
     if (plan != MS_CHUNKED) return 0;
     return (size_t)B * N * ms_chunks(N) * (d + 1) * sizeof(float);
 }
@@ -860,10 +883,13 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     const int S = ms_chunks(N);
     const size_t need = (size_t)B * N * S * (d + 1) * sizeof(float);
     const bool have_f16 = iters > 0 && workspace && d == 128 && workspace_bytes >= ms_f16_workspace_bytes(B, N);
-    const int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, g_ms_variant);
-    if (plan == MS_F16) {
+    int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, g_ms_variant);
+    if (plan == MS_F16_CHUNKED && workspace_bytes < ms_f16_chunked_workspace_bytes(B, N)) plan = MS_F16;
+    if (plan == MS_F16 || plan == MS_F16_CHUNKED) {
         int* flags = nullptr;
-        const int rc = ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, stream);
+        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, stream)
+                                      : ms_f16_chunked_launch(B, N, iters, bw, X, newX, workspace, &flags,
+                                                              ms_combine_launch, stream);
         if (rc != SED_OK) return rc;
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud

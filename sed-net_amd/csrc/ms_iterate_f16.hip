@@ -302,12 +302,19 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16_kernel(co
 //     block n + 1 (issued after B_{n-1}) and finished every read of block n - 1 (both groups are past its O-product), so
 //     after B_n the DMA of block n + 2 may overwrite buffer (n - 1) % 3 and block n + 1 may be read -- which is what the
 //     ring prefetch at the end of block n's O-product does.
-template <bool STAGGER>
+// CHUNKED (few clouds per call: 40 workgroups per 10 000-point cloud cannot fill 256 CUs): one workgroup = 256 queries x
+// ONE CHUNK of the stages x ONE iteration. Q is the current iterate `Qin` (fp32), the un-normalised partial (sum p x,
+// sum p) goes to a workspace and ms_combine_kernel (ms_iterate.hip) finishes the iteration, one launch pair per
+// iteration -- the schedule of ms_partial_d128_kernel with the split-fp16 inner loop.
+template <bool STAGGER, bool CHUNKED = false>
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
                                                                       const float* __restrict__ bw,
-                                                                      const int* __restrict__ flags, int N, int iters) {
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
@@ -319,11 +326,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
     int bx;
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
-    const float* Xc = X + (size_t)cloud * N * 128;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
     const int nst = (N + 31) >> 5;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
     const int qrow = bx * 256 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
 
     const float b = bw[cloud];
     const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
@@ -382,10 +391,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
         }
     };
 
-    const int total = iters * nst;
-    int st_cur = 0, st_dma = 0;
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once (advance() never
+    int st_cur = s0, st_dma = s0;                        // reaches a turning point inside the chunk's blocks)
     bool fwd_cur = true, fwd_dma = true;
-    if (total > 0) stage_dma(0, 0);
+    if (total > 0) stage_dma(s0, 0);
     advance(st_dma, fwd_dma);
     if (total > 1) stage_dma(st_dma, 1);
     advance(st_dma, fwd_dma);                            // st_dma = stage of block 2
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
         }
 
         // ---- end of a sweep: row update (mean_shift.py:70-77)
-        const bool sweep_end = fwd_cur ? st_cur == nst - 1 : st_cur == 0;
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
         advance(st_cur, fwd_cur);
         buf = nbuf;
         if (sweep_end) {
@@ -522,6 +531,24 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
                 rsum = 0.f;
             }
         }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
     }
     if (iters == 0 && qrow < N) {
         float* out = newX + ((size_t)cloud * N + qrow) * 128;
@@ -587,6 +614,55 @@ static int f16p_launch(int B, int N, int iters, const float* bw, const float* X,
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     ms_iterate_d128_f16p_kernel<STAGGER><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw,
                                                                                                   flags, N, iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// key-chunked split-fp16 schedule: chunk count from N only (results do not depend on how many clouds share a launch):
+// as many chunks as fill the 256 CUs with ONE cloud's workgroups, at least 8 stages per chunk; 0 = not worth it
+int ms_f16_chunks(int N) {
+    const int nbx = (N + 255) / 256, nst = (N + 31) / 32;
+    if (N < 2560) return 0;
+    int S = 256 / nbx;
+    if (S > nst / 8) S = nst / 8;
+    return S < 2 ? 0 : S;
+}
+
+size_t ms_f16_chunked_workspace_bytes(int B, int N) {
+    return ms_f16_workspace_bytes(B, N) + (size_t)B * N * ms_f16_chunks(N) * 129 * sizeof(float) + 256;
+}
+
+// one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher
+int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                          int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
+                                                          hipStream_t),
+                          hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
+    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + ms_f16_workspace_bytes(B, N)) + 255) & ~(uintptr_t)255);
+    float* partS = partO + (size_t)B * N * S * 128;
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    for (int it = 0; it < iters; ++it) {
+        const float* Q = it == 0 ? X : newX;
+        ms_iterate_d128_f16p_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, stream);
+        if (rc != SED_OK) return rc;
+    }
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -271,7 +271,7 @@ def test_bf16_layers_equal_fp32_layers_on_rounded_operands(T):
     eb, ef = run_e(True), run_e(False)
     frac = np.mean(np.abs(eb[0] - ef[0]) <= 3e-2 * np.abs(ef[0]).max())
     assert frac > 0.995, frac                                  # a max over k may pick another neighbour after rounding
-    close(eb[2], ef[2], 5e-2, "EdgeConv dW bf16 vs fp32")
+    _mostly_close(eb[2], ef[2], 5e-2, 0.995)               # EdgeConv dW bf16 vs fp32 (same allowance for switched slots)
 
 
 def test_bf16_training_tracks_fp32(T):

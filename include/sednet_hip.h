@@ -91,7 +91,7 @@ int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const fl
  * key sweep of every 128-query block over several workgroups per iteration so that all CUs have work. */
 size_t sed_ms_iterate_workspace_bytes(int B, int N, int d);
 /* the schedule sed_ms_iterate_ws_f32 takes for this shape when given that workspace: 1 batched fp32, 2 split-key fp32,
- * 3 key-chunked fp32, 4 split-fp16 (sed_ms_set_variant); 0 = unsupported shape */
+ * 3 key-chunked fp32, 4 split-fp16, 5 key-chunked split-fp16 (sed_ms_set_variant); 0 = unsupported shape */
 int sed_ms_iterate_plan(int B, int N, int d);
 int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                           void* workspace, size_t workspace_bytes, sed_stream_t stream);
@@ -116,7 +116,8 @@ int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, c
  * variant above), and split-fp16 (ms_iterate_f16.hip: the two fp32 products evaluated as 3 fp16 MFMAs each on round-to-
  * nearest (h, l) splits of the fp32 operands -- dropped terms <= 3 * 2^-24 relative, fp32 accumulation -- needs the
  * workspace; clouds whose rows are not unit vectors fall back to the fp32 kernel on the device). 0 = choose by size
- * (default: split-fp16 whenever the workspace is given), 1 = batched, 2 = split-key, 3 = key-chunked, 4 = split-fp16
+ * (default: split-fp16 whenever the workspace is given; its key-chunked form, one launch pair per iteration, when few
+ * clouds would leave CUs idle), 1 = batched, 2 = split-key, 3 = key-chunked, 4 = split-fp16, 5 = key-chunked split-fp16
  * (tests, measurements). */
 int sed_ms_set_variant(int variant);
 /* split-fp16 schedule: 0 = pipelined kernel (32-key stages, three LDS buffers, operand ring, wave groups half a block out

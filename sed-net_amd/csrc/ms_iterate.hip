@@ -20,6 +20,8 @@
 // Algorithmic work: 4 N^2 D flops per iteration per cloud; bound: fp32 MFMA.
 #include "common.h"
 
+int ms_f16_chunks(int N);      // ms_iterate_f16.hip: chunk count of the key-chunked split-fp16 schedule (0 = none)
+
 namespace {
 
 // exp(a) for a in [-75, 75] on the hardware exp2: t = RN(a * log2e), e = the rounding error of that product
@@ -793,8 +795,6 @@ int ms_chunks(int N) {
 }
 
 enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3, MS_F16 = 4, MS_F16_CHUNKED = 5 };
-
-int ms_f16_chunks(int N);      // ms_iterate_f16.hip
 
 // `have_ws`: a workspace large enough for the key-chunked partials; `have_f16`: one large enough for the split-fp16
 // stage images. The split-fp16 kernel (ms_iterate_f16.hip: 5.3 x less matrix time, fp32-equivalent error) is the

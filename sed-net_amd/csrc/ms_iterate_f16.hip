@@ -465,6 +465,9 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
         };
 
         if (!late) first_product_and_weights();
+        // this wave's pieces of block n + 1 (issued after B_{n-1}, a whole block ago) must have landed before it passes B_n:
+        // stated explicitly instead of relying on where the compiler drains vmcnt
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                  // B_n
         if (n + 2 < total) stage_dma(st_dma, buf == 0 ? 2 : buf - 1);       // block n + 2 -> buffer (n + 2) % 3
         advance(st_dma, fwd_dma);

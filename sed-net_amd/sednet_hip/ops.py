@@ -259,16 +259,16 @@ def ms_iterate(X, bw, iters):
         ev1.record()
         plan = lib.sed_ms_iterate_plan(B, N, D) if nws else 1
         TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters),
-                                                "schedule": "split-fp16" if plan == 4 else "fp32"}))
+                                                "schedule": "split-fp16" if plan in (4, 5) else "fp32"}))
     return out
 
 
 def ms_set_variant(variant):
     """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
-    "f16" (split-fp16 MFMA emulation, pipelined kernel; "f16i" = its wave groups in phase, "f16v1" / "f16b" = the first,
-    unpipelined version with 64-key / 32-key stages) (tests / measurements)."""
+    "f16" (split-fp16 MFMA emulation, pipelined kernel; "f16c" = its key-chunked form for few clouds per call, "f16i" =
+    wave groups in phase, "f16v1" / "f16b" = the first, unpipelined version with 64-key / 32-key stages)."""
     check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3}.get(variant, 0)), "ms_set_f16_config")
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3}.get(variant, 4)),
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5}.get(variant, 4)),
           "ms_set_variant")
 
 

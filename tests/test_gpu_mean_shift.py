@@ -44,7 +44,7 @@ def variant(request):
     ops.ms_set_variant("auto")
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b"], indirect=True)
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c"], indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
@@ -97,7 +97,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -111,6 +111,7 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_array_equal(res["f16"], res["f16i"])           # same arithmetic and order, different schedule
     np.testing.assert_array_equal(res["f16"], res["f16b"])
     np.testing.assert_allclose(res["f16"], res["f16v1"], atol=2e-6)  # 32- vs 64-key stages: order of the backward sweeps
+    np.testing.assert_allclose(res["f16"], res["f16c"], atol=2e-5)   # key-chunked: partial sums added per chunk
     assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16"]).all()
     one = {}
     try:

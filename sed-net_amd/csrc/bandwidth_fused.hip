@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     float q[F16 ? 1 : NT][16];
     h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
     float two_cq = 2.0f;
-    __shared__ float cks[2][32];
+    __shared__ __attribute__((aligned(16))) float cks[2][32];
     const float* invc = F16 ? inv + (size_t)cloud * N : nullptr;
     if (F16) {
         split_load_query<NT>((const h16*)Xc + (size_t)qrow_c * 2 * D, hi, qh, ql);
@@ -82,18 +82,21 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         if (F16 && tid < 32) cks[buf][tid] = stage_ck;
     };
 
-    uint32_t bm[PASS == 1 ? BM : 1][16];
+    // bucket minima as floats, float prefilter in sweep 2: see knn_fused.hip
+    float bm[PASS == 1 ? BM : 1][16];
     if (PASS == 1) {
 #pragma unroll
         for (int i = 0; i < BM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bm[i][r] = 0xFFFFFFFFu;
+            for (int r = 0; r < 16; ++r) bm[i][r] = 3.0e38f;
     }
     uint32_t T = 0;
+    float Tf = 0.f;
     int cnt = 0;
     uint32_t* mylist = nullptr;
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
+        Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);
         mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPK;
     }
 
@@ -121,23 +124,31 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
                 }
         }
         const bool ragged = (tile == ntiles - 1) && (N & 31);
+        f32x4 ck4[4];
+        if (F16) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][mfma_row(r, hi)] : 2.0f * s[r];
+            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
             const float dv = 2.0f - dot2;                                                // mean_shift.py:128
-            uint32_t key = f32_sortable(dv);
-            if (ragged && tile * 32 + mfma_row(r, hi) >= N) key = 0xFFFFFFFFu;
+            const bool pad = ragged && tile * 32 + mfma_row(r, hi) >= N;
             if (PASS == 1) {
+                float v = pad ? 3.0e38f : dv;
 #pragma unroll
                 for (int i = 0; i < BM; ++i) {
-                    const uint32_t lo_ = min(bm[i][r], key);
-                    key = max(bm[i][r], key);
+                    const float lo_ = fminf(bm[i][r], v);
+                    v = fmaxf(bm[i][r], v);
                     bm[i][r] = lo_;
                 }
             } else {
-                if (key <= T && key != 0xFFFFFFFFu) {
-                    if (cnt < CAPK) mylist[cnt] = key;
-                    ++cnt;
+                if (dv <= Tf && !pad) {
+                    const uint32_t key = f32_sortable(dv);
+                    if (key <= T) {
+                        if (cnt < CAPK) mylist[cnt] = key;
+                        ++cnt;
+                    }
                 }
             }
         }
@@ -148,6 +159,11 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
 
     if (PASS == 1) {
         // K-th smallest of this query's 32 * BM bucket values (this lane's + the partner lane's)
+        uint32_t bk[BM][16];
+#pragma unroll
+        for (int i = 0; i < BM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bk[i][r] = bm[i][r] >= 3.0e38f ? 0xFFFFFFFFu : f32_sortable(bm[i][r]);
         uint32_t lo = 0, hiv = 0xFFFFFFFFu;
         for (int it = 0; it < 32; ++it) {
             const uint32_t mid = lo + ((hiv - lo) >> 1);
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < BM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c += bm[i][r] <= mid ? 1 : 0;
+                for (int r = 0; r < 16; ++r) c += bk[i][r] <= mid ? 1 : 0;
             c += __shfl_xor(c, 32, 64);
             if (lo < hiv) { if (c >= K) hiv = mid; else lo = mid + 1; }
         }

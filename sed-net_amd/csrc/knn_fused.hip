@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;
     __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
-    __shared__ float xxs[2][32];
+    __shared__ __attribute__((aligned(16))) float xxs[2][32];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     int bxi;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     }
     const float xq = xxc[qrow_c];
     const float* invc = F16 ? inv + (size_t)cloud * N : nullptr;
-    __shared__ float cks[2][32];                           // 2^-e of the staged key rows (F16)
+    __shared__ __attribute__((aligned(16))) float cks[2][32];      // 2^-e of the staged key rows (F16)
 
     f32x4 stage[NT];
     float stage_xx = 0.f, stage_ck = 0.f;
@@ -94,18 +94,24 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
         if (tid < 32) { xxs[buf][tid] = stage_xx; if (F16) cks[buf][tid] = stage_ck; }
     };
 
-    uint32_t bm[M][16];
+    // sweep 1 keeps the bucket minima as FLOATS (v_min / v_max; converted to order-preserving keys once, for the
+    // bisection): any confusion of -0 / +0 in a float min only loosens the bound T, which stays a valid upper bound of
+    // the k-th smallest. Sweep 2 rejects with one float compare (a superset of key <= T for the same reason) and builds
+    // the key only for the ~0.4 % of elements that survive.
+    float bm[M][16];
     if (PASS == 1) {
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bm[i][r] = 0xFFFFFFFFu;
+            for (int r = 0; r < 16; ++r) bm[i][r] = 3.0e38f;
     }
     uint32_t T = 0;
+    float Tf = 0.f;
     int cnt = 0;
     Cand* mylist = nullptr;
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
+        Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);      // fewer than k bucket values: take everything
         mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPL;
     }
 
@@ -137,22 +143,33 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
                 }
         }
         const bool ragged = (tile == ntiles - 1) && (N & 31);
+        // per-key-row constants of this lane's 16 accumulator rows: rows 8 g + 4 hi .. + 3 are contiguous -> 4 + 4 vector reads
+        f32x4 xk4[4], ck4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xk4[g] = *(const f32x4*)&xxs[cur][8 * g + 4 * hi];
+            if (F16) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int krow = mfma_row(r, hi);
-            const float xk = xxs[cur][krow];
-            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][krow] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
+            const float xk = xk4[r >> 2][r & 3];
+            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
             const float t1 = __fadd_rn(-xk, dot2);               // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
-            const float dv = -__fsub_rn(t1, xq);                 // ... - xx_i ; distance = -score
-            uint32_t key = f32_sortable(far ? -dv : dv);         // far: the k LARGEST distances (smooth_normal_matrix.py:33-40)
-            if (ragged && tile * 32 + krow >= N) key = 0xFFFFFFFFu;
+            float dv = -__fsub_rn(t1, xq);                       // ... - xx_i ; distance = -score
+            if (far) dv = -dv;                                   // far: the k LARGEST distances (smooth_normal_matrix.py:33-40)
+            const bool pad = ragged && tile * 32 + krow >= N;
             if (PASS == 1) {
+                float v = pad ? 3.0e38f : dv;
 #pragma unroll
-                for (int i = 0; i < M; ++i) { const uint32_t lo_ = min(bm[i][r], key); key = max(bm[i][r], key); bm[i][r] = lo_; }
+                for (int i = 0; i < M; ++i) { const float lo_ = fminf(bm[i][r], v); v = fmaxf(bm[i][r], v); bm[i][r] = lo_; }
             } else {
-                if (key <= T && key != 0xFFFFFFFFu) {
-                    if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
-                    ++cnt;
+                if (dv <= Tf && !pad) {
+                    const uint32_t key = f32_sortable(dv);
+                    if (key <= T) {
+                        if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
+                        ++cnt;
+                    }
                 }
             }
         }
@@ -163,6 +180,11 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
 
     if (PASS == 1) {
         // k-th smallest of this query's 32 M bucket values (this lane's + the partner lane's)
+        uint32_t bk[M][16];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bk[i][r] = bm[i][r] >= 3.0e38f ? 0xFFFFFFFFu : f32_sortable(bm[i][r]);
         uint32_t lo = 0, hiv = 0xFFFFFFFFu;
         for (int it = 0; it < 32; ++it) {
             const uint32_t mid = lo + ((hiv - lo) >> 1);
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c += bm[i][r] <= mid ? 1 : 0;
+                for (int r = 0; r < 16; ++r) c += bk[i][r] <= mid ? 1 : 0;
             c += __shfl_xor(c, 32, 64);
             if (lo < hiv) { if (c >= k) hiv = mid; else lo = mid + 1; }
         }

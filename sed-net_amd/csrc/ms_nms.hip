@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
     float q[F16 ? 1 : NT][16];
     h16x8 qh[F16 ? 2 * NT : 1], ql[F16 ? 2 * NT : 1];
     float two_cq = 2.0f;
-    __shared__ float cks[2][32];
+    __shared__ __attribute__((aligned(16))) float cks[2][32];
     const float* cinvc = F16 ? cinv + (size_t)cloud * N : nullptr;
     if (F16) {
         split_load_query<NT>((const h16*)Xc + (size_t)prow_c * 2 * D, hi, qh, ql);
@@ -100,10 +100,15 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
                     for (int c = 0; c < 4; ++c) s = mfma32(xa[c], q[t][4 * g + c], s);   // centres on rows, points on lanes
                 }
         }
+        f32x4 ck4[4];
+        if (F16) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = tile * 32 + mfma_row(r, hi);
-            const float dot2 = F16 ? (s[r] * two_cq) * cks[cur][mfma_row(r, hi)] : 2.0f * s[r];
+            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
             const float dist = 2.0f - dot2;
             if (ci < N && (dist < best || (dist == best && ci < besti))) { best = dist; besti = ci; }
         }

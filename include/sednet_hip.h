@@ -179,6 +179,16 @@ size_t sed_pointwise_colext_bytes(int B, int N, int Coutp);
 int sed_pointwise_fwd_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const float* Wt,
                           const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
                           int flags, sed_stream_t stream);
+/* ---- inference GEMMs on the bf16 matrix pipe, fp32-equivalent (three-way bf16 splits v = b1 + b2 + b3, 6 bf16 MFMAs per
+ * product, dropped terms <= 2^-25 relative, fp32 accumulation, no scales; see pointwise_split_kernel) ----------------------
+ * sed_pointwise_split_weights_f32: W [Cout][K] fp32 (the Conv1d weight) -> `wsplit` (sed_pointwise_split_weights_bytes),
+ * once per model. sed_pointwise_fwd_split_f32: the contract of sed_pointwise_fwd_f32 with `wsplit` in place of Wt. */
+size_t sed_pointwise_split_weights_bytes(int Coutp, int K);
+int sed_pointwise_split_weights_f32(int Cout, int Coutp, int K, const float* W, int ldw, void* wsplit,
+                                    sed_stream_t stream);
+int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
+                                const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
+                                int flags, sed_stream_t stream);
 /* ---- training products (BASELINE configs[4]: bf16) ---------------------------------------------
  * sed_pointwise_fwd_bf16 / sed_edgeconv_fwd_train_bf16: the fp32 entry points' contracts with the products in bf16
  * (operands rounded to nearest even while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 / fp64 statistics;

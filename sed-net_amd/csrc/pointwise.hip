@@ -15,6 +15,7 @@
 // SEDNet.py:322,326). For mlp1 only max_N relu(GN(y)) is needed, and relu(affine) is monotone per channel,
 // so the epilogue keeps per-channel max/min over the tile instead of writing the [N,1024] tensor.
 #include "common.h"
+#include "split16.h"
 
 namespace {
 
@@ -22,6 +23,7 @@ enum { F_RELU = 1, F_STORE = 2, F_STATS = 4, F_COLEXT = 8 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // BF16 (training, BASELINE configs[4]): both operands are rounded to bf16 (round to nearest even) while they are staged
 // into LDS and the products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias, statistics (fp64 partials) and
@@ -175,6 +177,183 @@ __global__ __launch_bounds__(256, 2) void pointwise_kernel(const float* __restri
         float mx = -3.0e38f, mn = 3.0e38f;
         for (int w = 0; w < 4; ++w) { mx = fmaxf(mx, ext[(w * BN + tid) * 2]); mn = fminf(mn, ext[(w * BN + tid) * 2 + 1]); }
         float* dst = colext + (((size_t)cloud * gridDim.x + blockIdx.x) * ldw + o0 + tid) * 2;
+        dst[0] = mx;
+        dst[1] = mn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Inference GEMMs on the bf16 matrix pipe with fp32-equivalent results (round 2): three-way bf16 splits.
+//     v = b1 + b2 + b3 + r,   b1 = bf16(v), b2 = bf16(v - b1), b3 = bf16(v - b1 - b2),   |r| <= 2^-27 |v|
+// (bf16 keeps fp32's exponent, so no scaling and no bound on the activations is needed -- the split-fp16 scheme of the
+// mean-shift kernels needs a per-row scale, and measured here its max / scale / rescale work made the kernel VALU-bound:
+// 16 VALU instructions per MFMA, no faster than fp32). A product x w is evaluated as
+//     x1 w3 + x3 w1 + x2 w2 + x1 w2 + x2 w1 + x1 w1
+// -- six bf16 MFMAs per 16 k (products of two 8-bit significands are exact in the fp32 accumulator); dropped: x2 w3 + x3 w2
+// + x3 w3 + the representation error, <= 2^-25 |x w|: below ONE fp32 rounding, where the fp32 fma chain rounds K times.
+// Matrix time: 6 x 32 cycles per 16 k against 8 x 64 cycles for v_mfma_f32_32x32x2_f32 = 0.375 x.
+// The weights arrive pre-split (three planes [Coutp][K] bf16, k-contiguous) and are staged through a double-buffered LDS
+// ring (row stride 80 B: one conflict-free ds_read_b128 per operand). A wave owns 32 points x BN channels, so an
+// activation is needed by ONE wave only: every lane reads the 8 consecutive k of its MFMA operand straight from global
+// memory (two 16-byte loads per 16 k, prefetched one chunk ahead) and splits them in registers -- no LDS round trip.
+// Workgroups that share an X tile (same points, different channel block) get consecutive slots on the SAME XCD, so that X
+// is read from HBM once and from that XCD's L2 afterwards. Epilogue identical to pointwise_kernel.
+__device__ __forceinline__ void split3(const f32x4& lo, const f32x4& hi4, bf16x8& b1, bf16x8& b2, bf16x8& b3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? lo[e & 3] : hi4[e & 3];
+        const __bf16 p1 = (__bf16)v;
+        const float r1 = v - (float)p1;
+        const __bf16 p2 = (__bf16)r1;
+        const float r2 = r1 - (float)p2;
+        b1[e] = p1;
+        b2[e] = p2;
+        b3[e] = (__bf16)r2;
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __restrict__ X, int ldx, int K,
+                                                                 const __bf16* __restrict__ Wp /* [3][Coutp][K] */,
+                                                                 int Coutp, const float* __restrict__ bias,
+                                                                 const float* __restrict__ cbias, float* __restrict__ Y,
+                                                                 int ldy, int Cout, double* __restrict__ part,
+                                                                 float* __restrict__ colext, int N, int nblk, int flags) {
+    constexpr int BN = 32 * TN;
+    constexpr int LDH = 40;                                  // bf16 per LDS row (32 k + 8 pad = 80 B)
+    constexpr int NB = 3 * BN * 4 / 256;                     // 16-byte pieces of one weight stage per thread (6 / 3)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Bs = (__bf16*)smem;                              // [2][3][BN][LDH]
+    double* red = (double*)(Bs + 2 * 3 * BN * LDH);          // [4][TN][2]
+    float* ext = (float*)(red + 4 * TN * 2);                 // [4][BN][2]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    // slot -> (point tile, channel block): slots L, L + 8, L + 16, ... run on XCD L % 8; consecutive slots of one XCD walk
+    // the channel blocks of one point tile first
+    const int nz = Coutp / BN;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int zb = j % nz, pt = (j / nz) * 8 + xcd;
+    if (pt >= nblk) return;
+    const int cloud = blockIdx.y, o0 = zb * BN;
+    const int p0 = pt * 128;
+    const float* Xc = X + (size_t)cloud * N * ldx;
+    const int nchunk = K / 32;
+    const size_t plane = (size_t)Coutp * K;
+
+    int prow = p0 + wave * 32 + li;
+    if (prow >= N) prow = N - 1;
+    const float* xrow = Xc + (size_t)prow * ldx + 8 * hi;
+    // activations are prefetched TWO chunks ahead (the X stream comes from HBM: one chunk of matrix work, ~0.7 us, does not
+    // cover its latency); the weight planes (L2-resident) one chunk ahead
+    f32x4 xa0[4], xa1[4];                                    // [k-step][first / second float4]
+    auto load_a = [&](int ch, f32x4* xa) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xa[u] = *(const f32x4*)(xrow + ch * 32 + 16 * (u >> 1) + 4 * (u & 1));
+    };
+    u32x4 sb[NB];
+    auto load_b = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u, pl = i / (BN * 4), row = (i / 4) % BN, seg = i & 3;
+            sb[u] = *(const u32x4*)(Wp + pl * plane + (size_t)(o0 + row) * K + ch * 32 + 8 * seg);
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u, pl = i / (BN * 4), row = (i / 4) % BN, seg = i & 3;
+            *(u32x4*)(Bs + ((buf * 3 + pl) * BN + row) * LDH + 8 * seg) = sb[u];
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto step = [&](int ch, f32x4* xa, int cur) {
+        bf16x8 a1[2], a2[2], a3[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) split3(xa[2 * s2], xa[2 * s2 + 1], a1[s2], a2[s2], a3[s2]);
+        if (ch + 2 < nchunk) load_a(ch + 2, xa);
+        if (ch + 1 < nchunk) load_b(ch + 1);
+        const __bf16* b1p = Bs + ((cur * 3 + 0) * BN + li) * LDH + hi * 8;
+        const __bf16* b2p = b1p + BN * LDH;
+        const __bf16* b3p = b2p + BN * LDH;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const bf16x8 w1 = *(const bf16x8*)(b1p + 32 * t * LDH + 16 * s2);
+                const bf16x8 w2 = *(const bf16x8*)(b2p + 32 * t * LDH + 16 * s2);
+                const bf16x8 w3 = *(const bf16x8*)(b3p + 32 * t * LDH + 16 * s2);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w3, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s2], w1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w1, acc[t], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunk) store_b(cur ^ 1);
+        __syncthreads();
+    };
+
+    load_a(0, xa0);
+    if (nchunk > 1) load_a(1, xa1);
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        step(ch, xa0, 0);
+        if (ch + 1 < nchunk) step(ch + 1, xa1, 1);
+    }
+
+    // ---- epilogue (pointwise_kernel's)
+    const int pw = p0 + wave * 32;
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vmask |= (pw + mfma_row(r, hi) < N ? 1u : 0u) << r;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int o = o0 + 32 * t + li;
+        float add = bias ? bias[o] : 0.f;
+        if (cbias) add += cbias[(size_t)cloud * Coutp + o];
+        float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[t][r] + add;
+            if (flags & F_RELU) v = fmaxf(v, 0.f);
+            const bool ok = (vmask >> r) & 1u;
+            if ((flags & F_STORE) && ok && o < Cout)
+                Y[((size_t)cloud * N + pw + mfma_row(r, hi)) * ldy + o] = v;
+            if (ok) { ps += v; pq = fmaf(v, v, pq); mx = fmaxf(mx, v); mn = fminf(mn, v); }
+        }
+        if (flags & F_STATS) {
+            double d1 = (double)ps, d2 = (double)pq;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+            if (lane == 0) { red[(wave * TN + t) * 2] = d1; red[(wave * TN + t) * 2 + 1] = d2; }
+        }
+        if (flags & F_COLEXT) {
+            mx = fmaxf(mx, xor32(mx));
+            mn = fminf(mn, xor32(mn));
+            if (hi == 0) { ext[(wave * BN + 32 * t + li) * 2] = mx; ext[(wave * BN + 32 * t + li) * 2 + 1] = mn; }
+        }
+    }
+    if (flags & (F_STATS | F_COLEXT)) __syncthreads();
+    if ((flags & F_STATS) && tid < TN * 2) {
+        const int t = tid >> 1, which = tid & 1;
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += red[(w * TN + t) * 2 + which];
+        const int ntile = nz * TN;
+        part[(((size_t)cloud * nblk + pt) * ntile + zb * TN + t) * 2 + which] = s;
+    }
+    if ((flags & F_COLEXT) && tid < BN) {
+        float mx = -3.0e38f, mn = 3.0e38f;
+        for (int w = 0; w < 4; ++w) { mx = fmaxf(mx, ext[(w * BN + tid) * 2]); mn = fminf(mn, ext[(w * BN + tid) * 2 + 1]); }
+        float* dst = colext + (((size_t)cloud * nblk + pt) * Coutp + o0 + tid) * 2;
         dst[0] = mx;
         dst[1] = mn;
     }
@@ -345,6 +524,74 @@ static int pointwise_fwd(int B, int N, int K, int Coutp, int Cout, const float* 
         else
             pointwise_kernel<2, false><<<dim3(nblk, B, Coutp / 64), 256, sm, stream>>>(
                 X, ldx, K, Wt, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, flags);
+    }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// Pre-split weights for sed_pointwise_fwd_split_f32: W [Cout][K] fp32 (row stride ldwin) -> three bf16 planes [Coutp][K]
+// (rows >= Cout: zeros).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, int ldwin, int Cout, int Coutp,
+                                                            int K, __bf16* __restrict__ Wp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Coutp * K) return;
+    const int o = (int)(i / K), k = (int)(i % K);
+    const float v = o < Cout ? W[(size_t)o * ldwin + k] : 0.f;
+    const __bf16 p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    const size_t plane = (size_t)Coutp * K;
+    Wp[i] = p1;
+    Wp[plane + i] = p2;
+    Wp[2 * plane + i] = (__bf16)r2;
+}
+
+extern "C" size_t sed_pointwise_split_weights_bytes(int Coutp, int K) {
+    return (size_t)Coutp * K * 3 * sizeof(__bf16);
+}
+
+// W [Cout][K] (the Conv1d weight, row stride ldw >= K) -> split image in `wsplit` (sed_pointwise_split_weights_bytes).
+// Done once per model by the caller (weights are static at inference).
+extern "C" int sed_pointwise_split_weights_f32(int Cout, int Coutp, int K, const float* W, int ldw, void* wsplit,
+                                               hipStream_t stream) {
+    if (Cout <= 0 || Coutp < Cout || K <= 0 || K % 32 != 0 || !W || !wsplit || ldw < K) return SED_EINVAL;
+    const size_t n = (size_t)Coutp * K;
+    split_weights_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(W, ldw, Cout, Coutp, K, (__bf16*)wsplit);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// sed_pointwise_fwd_f32 with the products on the bf16 matrix pipe (three-way split, fp32-equivalent; see
+// pointwise_split_kernel). wsplit = the image written by sed_pointwise_split_weights_f32 for the same (Coutp, K).
+extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
+                                           const void* wsplit, const float* bias, const float* cbias, float* Y, int ldy,
+                                           void* partials, void* colext, int flags, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !X || !wsplit) return SED_EINVAL;
+    if (K % 32 != 0 || Coutp % 64 != 0 || ldx % 4 != 0 || ldx < K || Cout > Coutp) return SED_EUNSUPPORTED;
+    if ((flags & F_STORE) && (!Y || ldy < Cout)) return SED_EINVAL;
+    if ((flags & F_STATS) && !partials) return SED_EINVAL;
+    if ((flags & F_COLEXT) && !colext) return SED_EINVAL;
+    const int nblk = (N + 127) / 128;
+    const int nblk8 = (nblk + 7) / 8 * 8;
+    auto smem = [](int BN, int TN) {
+        return (size_t)(2 * 3 * BN * 40) * sizeof(__bf16) + 4 * TN * 2 * sizeof(double) + 4 * BN * 2 * sizeof(float);
+    };
+    if (Coutp % 128 == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        pointwise_split_kernel<4><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
+            X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
+            flags);
+    } else {
+        pointwise_split_kernel<2><<<dim3(nblk8 * (Coutp / 64), B), 256, smem(64, 2), stream>>>(
+            X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
+            flags);
     }
     SED_LAUNCH_CHECK();
     return SED_OK;

@@ -62,6 +62,9 @@ SIGNATURES = {
     "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_colext_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_pointwise_split_weights_bytes": (c_size_t, [c_int, c_int]),
+    "sed_pointwise_split_weights_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P]),
+    "sed_pointwise_fwd_split_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
     "sed_pointwise_fwd_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
     "sed_edgeconv_fwd_train_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,
                                             P, P, P, c_size_t, P]),

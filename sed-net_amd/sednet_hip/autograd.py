@@ -80,7 +80,7 @@ class ConvGNAct(torch.autograd.Function):
             bp[:Cout] = bias.detach().float()
         cb = cbias.detach().float().contiguous() if cbias is not None else None
         Y, stats, _ = ops.pointwise(Xd, _wt_pad(W), Cout, bias=bp, cbias=cb, flags=ops.F_STORE | ops.F_STATS, G=G,
-                                    eps=eps, bf16=ops.TRAIN_BF16)
+                                    eps=eps, bf16=ops.TRAIN_BF16, split=False)      # weights change every step: no cached split
         out = torch.empty((Y.shape[0], Y.shape[1], Cout), dtype=torch.float32, device=Y.device)
         ops.gn_apply(Y, Cout, G, stats, g, b, act, out)
         ctx.save_for_backward(Xd, W, g, b, Y, stats)

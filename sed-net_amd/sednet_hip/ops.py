@@ -387,6 +387,7 @@ def _vptr(t):
     return _lib.c_void_p(t.data_ptr())
 
 
+POINTWISE_SPLIT = True  # inference GEMMs on the bf16 matrix pipe (3-way bf16 splits, fp32-equivalent); False: fp32 MFMA chains
 TRAIN_BF16 = False      # training products in bf16 (operands rounded while staged, fp32 accumulate): BASELINE configs[4]
 
 
@@ -409,9 +410,23 @@ def gemm(A, B, transA=False, transB=False, bf16=None):
     return C
 
 
-def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False):
+def _split_weights(Wt):
+    """three-plane bf16 split image of a weight matrix given in the kernel layout Wt [K,Coutp]; cached on the tensor object (the
+    models keep their Wt tensors until the parameters change, src/SEDNet.py:_prepared)."""
+    ws = getattr(Wt, "_sed_split", None)
+    if ws is None:
+        K, Coutp = Wt.shape
+        W = Wt.t().contiguous()                                           # [Coutp, K] = the Conv1d layout
+        ws = torch.empty((lib.sed_pointwise_split_weights_bytes(Coutp, K),), dtype=torch.uint8, device=Wt.device)
+        check(lib.sed_pointwise_split_weights_f32(Coutp, Coutp, K, ptr(W), K, ptr(ws), stream()), "split_weights")
+        Wt._sed_split = ws
+    return ws
+
+
+def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None):
     """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp]. bf16: products in bf16
-    (training). Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
+    (training). split (default POINTWISE_SPLIT): products by 3-way bf16 split emulation on the bf16 matrix pipe.
+    Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
     B, N = X.shape[0], X.shape[1]
     K, Coutp = Wt.shape
     dev = X.device
@@ -419,8 +434,14 @@ def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, 
         out = torch.empty((B, N, Coutp), dtype=torch.float32, device=dev)[:, :, :Cout]
     part = _bytes(lib.sed_pointwise_partials_bytes(B, N, Coutp), dev) if flags & F_STATS else None
     colext = _bytes(lib.sed_pointwise_colext_bytes(B, N, Coutp), dev) if flags & F_COLEXT else None
-    fwd = lib.sed_pointwise_fwd_bf16 if bf16 else lib.sed_pointwise_fwd_f32
-    check(fwd(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), ptr(Wt),
+    split = POINTWISE_SPLIT if split is None else split
+    if bf16:
+        fwd, wptr = lib.sed_pointwise_fwd_bf16, ptr(Wt)
+    elif split:
+        fwd, wptr = lib.sed_pointwise_fwd_split_f32, ptr(_split_weights(Wt))
+    else:
+        fwd, wptr = lib.sed_pointwise_fwd_f32, ptr(Wt)
+    check(fwd(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), wptr,
               ptr(bias) if bias is not None else None, ptr(cbias) if cbias is not None else None,
               _vptr(out) if out is not None else None, out.stride(1) if out is not None else 0,
               ptr(part) if part is not None else None, ptr(colext) if colext is not None else None, flags, stream()),

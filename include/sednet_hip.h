@@ -111,6 +111,15 @@ int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, c
 int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                               float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
                               const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
+/* The same block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel):
+ * contract of sed_ms_iterate_bounds_f32 + a workspace (stage images of the sorted rows) and optional statistics -- 4 device
+ * uint64 counters that are ADDED to: stage visits of workgroups, first products of waves, second products of waves, and
+ * stages x iterations per wave (the dense count). Clouds whose rows are not unit vectors run the exact dense fp32 kernel. */
+size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
+int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
+                                  float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
+                                  const float* piv, const float* pang, int P, float margin, void* workspace,
+                                  size_t workspace_bytes, void* stats, sed_stream_t stream);
 /* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
  * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
  * variant above), and split-fp16 (ms_iterate_f16.hip: the two fp32 products evaluated as 3 fp16 MFMAs each on round-to-

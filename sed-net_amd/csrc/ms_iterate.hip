@@ -836,6 +836,12 @@ size_t ms_f16_workspace_bytes(int B, int N);
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                   int** flags_out, hipStream_t stream);
 
+size_t ms_f16_sparse_workspace_bytes(int B, int N);
+int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                         int** flags_out, float skip_below, const int* row_piv, const int* tile_rp,
+                         const float* tile_alpha, const float* piv, const float* pang, int P, float margin,
+                         unsigned long long* stats, hipStream_t stream);
+
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
                              hipStream_t stream) {
     ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, 128);
@@ -985,6 +991,44 @@ extern "C" int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const f
         attr_set = true;
     }
     ms_iterate_d128_kernel<true><<<dim3((N + 127) / 128, B), 256, sm, stream>>>(X, newX, bw, N, iters, skip_below);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// ---- block-sparse split-fp16 schedule (ms_iterate_f16.hip: ms_iterate_d128_f16s_kernel) ------------------------------
+// Contract of sed_ms_iterate_bounds_f32 (ms_sparse.hip: rows sorted into cluster-pure 32-row tiles + the pivot side
+// tables) with the products on the fp16 matrix pipe; workspace = sed_ms_iterate_bounds_f16_workspace_bytes(B, N);
+// stats: NULL or 4 device uint64 counters that are ADDED to (workgroup stage visits, wave first products, wave second
+// products, stages x iterations per wave = the dense count). Clouds whose rows are not unit vectors run the exact dense
+// fp32 kernel instead (same flag as the dense split-fp16 schedule).
+extern "C" size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return ms_f16_sparse_workspace_bytes(B, N);
+}
+
+extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X,
+                                             float* newX, float skip_below, const int* row_piv, const int* tile_rp,
+                                             const float* tile_alpha, const float* piv, const float* pang, int P,
+                                             float margin, void* workspace, size_t workspace_bytes, void* stats,
+                                             hipStream_t stream) {
+    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !row_piv || !tile_rp ||
+        !tile_alpha || !piv || !pang || P <= 0 || margin < 0.f || !workspace)
+        return SED_EINVAL;
+    if (d != 128) return SED_EUNSUPPORTED;
+    if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
+    int* flags = nullptr;
+    const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, row_piv, tile_rp,
+                                        tile_alpha, piv, pang, P, margin, (unsigned long long*)stats, stream);
+    if (rc != SED_OK) return rc;
+    constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
+    static bool attr_fb = false;
+    if (!attr_fb) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        attr_fb = true;
+    }
+    ms_iterate_d128_kernel<false><<<dim3((N + 127) / 128, B), 256, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -560,6 +560,339 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Block-sparse schedule on the pipelined split-fp16 kernel (round 2; the fp32 version is ms_sparse.hip).
+// Rows arrive sorted so that every 32-row tile -- here: every stage image -- is cluster-pure, with the geometric side
+// tables of sed_ms_iterate_bounds_f32 (nearest pivot of every row, reference pivot + cap angle alpha of every tile,
+// pivot-pivot angles). Every iteration
+//   (1) a query row measures beta = its current angle to its own pivot (fp32, from the split registers);
+//   (2) every wave marks the stages it needs: angle(P_row, P_tile) - beta - alpha_tile < theta, theta = the angle at which the
+//       kernel weight drops to e^skip (triangle inequality on the unit sphere: everything else carries weights <= e^skip);
+//   (3) the workgroup compacts the union of its 8 waves' marks into a stage list (thread s owns stage s: nst <= 512);
+//   (4) the pipeline of ms_iterate_d128_f16p_kernel runs over that list only -- stages nobody needs are never copied to
+//       LDS; a wave that does not need a listed stage only takes part in its barrier; a wave whose weights of a stage all
+//       round to zero in fp16 (p 2^14 <= 2^-25: exactly the blocks whose O-contribution is 0 in the dense kernel too)
+//       skips the second product.
+// The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
+// direction so that an iteration starts on the stages the previous one left in L2.
+// What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
+constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const int* __restrict__ row_piv, const int* __restrict__ tile_rp, const float* __restrict__ tile_alpha,
+    const float* __restrict__ piv, const float* __restrict__ pang, int P, float margin,
+    unsigned long long* __restrict__ stats) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    constexpr int MAXW = F16S_MAXW;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    __shared__ unsigned long long wmask[8][MAXW];
+    __shared__ int slist[512];
+    __shared__ int wcount[8];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const bool late = STAGGER && wave >= 4;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + 31) >> 5;
+    const int nword = (nst + 63) >> 6;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+    const float Dthr = -2.0f * skip_below * b * b;       // dist >= Dthr  <=>  weight <= e^skip
+    const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin : 1.0e9f;     // 1e9: never skip
+    const int* rpc = tile_rp + (size_t)cloud * nst;
+    const float* alc = tile_alpha + (size_t)cloud * nst;
+    const int myp = row_piv[(size_t)cloud * N + qrow_c];
+    const float* mypiv = piv + ((size_t)cloud * P + myp) * 128;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+
+    h16x8 fa[4], fb[4];
+    const int xoff = li * XROW + hi * 16;
+    const int toff = li * TROW + hi * 16;
+    auto ring_load = [&](int t, const uint8_t* base) {
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    h16x8 ph[2], pl[2];
+    unsigned long long n_listed = 0, n_first = 0, n_second = 0;      // per-wave counts (statistics only)
+
+    for (int it = 0; it < iters; ++it) {
+        // ---- (1) beta: this row's angle to its pivot
+        float dp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 pv = *(const f32x4*)(mypiv + 16 * ks + 8 * g + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    dp = fmaf((float)qh[ks][4 * g + u] + (float)ql[ks][4 * g + u], pv[u], dp);
+            }
+        dp *= UNSCALE_Q;
+        dp += xor32(dp);
+        const float beta_i = qrow < N ? acosf(fminf(fmaxf(dp, -1.0f), 1.0f)) : -1.0e9f;
+        // ---- (2) this wave's stage mask: one pass per DISTINCT pivot among its rows, stages across lanes
+        if (lane < MAXW) wmask[wave][lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(qrow < N);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int a = __builtin_amdgcn_readlane(myp, leader);
+            const bool mine = myp == a && qrow < N;
+            float beta = mine ? beta_i : -1.0e9f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) beta = fmaxf(beta, __shfl_xor(beta, off, 64));
+            const float* ang = pang + ((size_t)cloud * P + a) * P;
+            unsigned long long mw[MAXW];
+#pragma unroll
+            for (int w = 0; w < MAXW; ++w) {
+                const int t = w * 64 + lane;
+                bool need = false;
+                if (w < nword && t < nst) need = !(ang[rpc[t]] - beta - alc[t] >= theta);
+                mw[w] = __builtin_amdgcn_ballot_w64(need);
+            }
+#pragma unroll
+            for (int w = 0; w < MAXW; ++w)
+                if (lane == w) wmask[wave][w] |= mw[w];
+            todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        }
+        __syncthreads();
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
+        int ns;
+        {
+            bool need = false;
+            if (tid < nst) {
+                const int w = tid >> 6, sh = tid & 63;
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) any |= wmask[v][w];
+                need = (any >> sh) & 1ull;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = 0;
+            ns = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int cnt = wcount[w];
+                if (w < wave) base += cnt;
+                ns += cnt;
+            }
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tid;
+        }
+        __syncthreads();
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        n_listed += ns;
+
+        // ---- (4) the pipeline over the list
+        const bool fwd = (it & 1) == 0;
+        auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
+        if (ns > 0) stage_dma(entry(0), 0);
+        if (ns > 1) stage_dma(entry(1), 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ns > 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) ring_load(t, lds);
+        }
+        int buf = 0;
+        for (int j = 0; j < ns; ++j) {
+            const uint8_t* base = lds + buf * STAGE;
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const uint8_t* nbase = lds + nbuf * STAGE;
+            const int st = entry(j);
+            const int key0 = st * 32;
+            const bool need =
+                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            bool live = false;
+
+            auto first_product_and_weights = [&]() {
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s = mfma16(fb[t & 3], qh[t], s);
+                    s = mfma16(fa[t & 3], ql[t], s);
+                    s = mfma16(fa[t & 3], qh[t], s);
+                    ring_load(t + 3, base);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                }
+                float pmax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    rsum += p[r];
+                    pmax = fmaxf(pmax, p[r]);
+                    const h16 h = (h16)p[r];
+                    ph[r >> 3][r & 7] = h;
+                    pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                }
+                // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
+                live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
+                ++n_first;
+            };
+
+            if (!late && need) first_product_and_weights();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // B_j
+            if (j + 2 < ns) stage_dma(entry(j + 2), buf == 0 ? 2 : buf - 1);
+            if (late && need) first_product_and_weights();
+
+            if (live) {
+                ++n_second;
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    const int c = (t - 8) >> 1, jj = (t - 8) & 1;
+                    o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if (t + 3 < 16) ring_load(t + 3, base);
+                    else if (j + 1 < ns) ring_load(t + 3 - 16, nbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (j + 1 < ns) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ring_load(t, nbase);
+            }
+            buf = nbuf;
+        }
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+    if (stats && lane == 0) {
+        // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
+        // [3] dense count: waves x stages x iterations
+        if (wave == 0) atomicAdd(stats + 0, n_listed);
+        atomicAdd(stats + 1, n_first);
+        atomicAdd(stats + 2, n_second);
+        atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
+    }
+}
+
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
@@ -682,6 +1015,41 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
     return g_ms_f16_cfg == 0 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
                              : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
+}
+
+
+size_t ms_f16_sparse_workspace_bytes(int B, int N) {
+    return f16_blob_bytes(B, N, 0) + (((size_t)B * sizeof(int) + 255) / 256) * 256;
+}
+
+// Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles (side tables as sed_ms_iterate_bounds_f32).
+// workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 4 x u64, accumulated).
+int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                         int** flags_out, float skip_below, const int* row_piv, const int* tile_rp,
+                         const float* tile_alpha, const float* piv, const float* pang, int P, float margin,
+                         unsigned long long* stats, hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32;
+    if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16s_kernel<true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, skip_below, row_piv, tile_rp, tile_alpha, piv, pang, P, margin, stats);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {

@@ -162,7 +162,25 @@ def ms_bandwidth(X, K, min_bw=0.003):
     return bw
 
 
-MS_SPARSE_SKIP = None      # e.g. -30.0: opt into the block-sparse schedule (ms_iterate_sparse) for d = 128
+# Block-sparse mean-shift schedule (d = 128, ms_iterate_sparse): "auto" = per cloud, by a density probe (ms_near_fraction:
+# the share of sampled row pairs whose kernel weight exceeds e^MS_SPARSE_SKIP; clustered embeddings -- what a trained
+# network produces -- sit near 1 / #clusters, unstructured ones near 1); "on" / "off" force it. The decision is a function
+# of the cloud alone, so results do not depend on which clouds share a batch.
+MS_SPARSE = "auto"
+MS_SPARSE_SKIP = -30.0
+MS_SPARSE_MAX_NEAR = 0.3
+MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
+_MS_VARIANT = "auto"
+
+
+def ms_near_fraction(X, bw, skip_below=-30.0, rows=64, keys=512):
+    """[B] share of (sampled row, sampled key) pairs with exp(-dist / (2 b^2)) > e^skip_below, dist = 2 - 2 x.y."""
+    B, N, D = X.shape
+    qi = torch.linspace(0, N - 1, min(rows, N), device=X.device).long()
+    ki = torch.linspace(0, N - 1, min(keys, N), device=X.device).long()
+    dist = 2.0 - 2.0 * torch.bmm(X[:, qi], X[:, ki].transpose(1, 2))
+    thr = (-2.0 * skip_below) * bw * bw
+    return (dist < thr.view(B, 1, 1)).float().mean((1, 2))
 
 
 def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
@@ -201,11 +219,13 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P))
 
 
-def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3):
+def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3, f16=True, stats=None):
     """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
     are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
     caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
-    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only."""
+    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
+    f16 (with bounds): products on the fp16 matrix pipe (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional
+    int64 [4] device tensor the kernel adds its visit counts to."""
     B, N, D = X.shape
     order, piv, sdots = ms_pivot_order(X, n_pivots)
     gidx = order.unsqueeze(-1).expand(B, N, D)
@@ -228,7 +248,14 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, 
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if use_bounds:
+    if use_bounds and f16:
+        nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=X.device)
+        check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                                ptr(rowp), ptr(rp32), ptr(alpha), ptr(piv), ptr(pang), P, float(margin),
+                                                ptr(ws), nws, ptr(stats) if stats is not None else None, stream()),
+              "ms_iterate_bounds_f16")
+    elif use_bounds:
         check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
                                             ptr(rowp), ptr(rp32), ptr(alpha), ptr(piv), ptr(pang), P, float(margin),
                                             stream()),
@@ -245,8 +272,27 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, 
 def ms_iterate(X, bw, iters):
     """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79)."""
     B, N, D = X.shape
-    if MS_SPARSE_SKIP is not None and D == 128 and iters > 0:
-        return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+    if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D == 128 and iters > 0 and 1024 <= N <= 16384:
+        if MS_SPARSE == "on":
+            return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+        sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < MS_SPARSE_MAX_NEAR).cpu()       # one small D->H copy
+        ns = int(sparse.sum())
+        MS_SPARSE_STATS["sparse_clouds"] += ns
+        MS_SPARSE_STATS["dense_clouds"] += B - ns
+        if ns == B:
+            return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+        if ns > 0:
+            si = torch.nonzero(sparse).squeeze(1).to(X.device)
+            di = torch.nonzero(~sparse).squeeze(1).to(X.device)
+            out = torch.empty_like(X)
+            out[si] = ms_iterate_sparse(X[si], bw[si].contiguous(), iters, MS_SPARSE_SKIP)
+            out[di] = _ms_iterate_dense(X[di], bw[di].contiguous(), iters)
+            return out
+    return _ms_iterate_dense(X, bw, iters)
+
+
+def _ms_iterate_dense(X, bw, iters):
+    B, N, D = X.shape
     out = torch.empty_like(X)
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -267,6 +313,8 @@ def ms_set_variant(variant):
     """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
     "f16" (split-fp16 MFMA emulation, pipelined kernel; "f16c" = its key-chunked form for few clouds per call, "f16i" =
     wave groups in phase, "f16v1" / "f16b" = the first, unpipelined version with 64-key / 32-key stages)."""
+    global _MS_VARIANT
+    _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
     check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3}.get(variant, 0)), "ms_set_f16_config")
     check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5}.get(variant, 4)),
           "ms_set_variant")

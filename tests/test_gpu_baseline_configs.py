@@ -39,12 +39,13 @@ def best_match_rate(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ configs[0]
-@pytest.mark.parametrize("variant", ["f16", "batched"])
+@pytest.mark.parametrize("variant", ["f16", "batched", "sparse"])
 def test_config0_single_10k_cloud_against_the_reference(T, golden, variant, capsys):
     """The contract's own numbers at N = 10 000 (north_star: "bit-exact segment indices after label canonicalisation ...
     seg-IoU within 1e-3 of reference"): exact-match rate of types and labels against the reference's outputs and the
     seg-IoU delta, for the script's flow on bench cloud 0 and for the clustering stage on an embedding with realistic
-    structure (13 clusters, a close pair, 4 % bridge points). Both mean-shift arithmetics (split-fp16 and exact fp32)."""
+    structure (13 clusters, a close pair, 4 % bridge points). Both mean-shift arithmetics (split-fp16 and exact fp32)
+    and the block-sparse split-fp16 schedule."""
     from oracle.mean_shift import canonical_labels
     from sednet_hip import ops, synth
     from src.mean_shift import MeanShift
@@ -77,13 +78,17 @@ def test_config0_single_10k_cloud_against_the_reference(T, golden, variant, caps
             else:
                 return float(bw), ids.cpu().numpy(), passes
     try:
-        ops.ms_set_variant(variant)
+        if variant == "sparse":                                # block-sparse split-fp16 schedule forced on both embeddings
+            ops.MS_SPARSE = "on"
+        else:
+            ops.ms_set_variant(variant)
         bw, ids, passes = guard(X)
         X2, _ = synth.realistic_embedding(N=N, d=128, n_clusters=14, sigma=0.02, bridge=0.04, seed=7)
         assert abs(X2.astype(np.float64).sum() - float(g["r_x_sum"])) < 1e-3
         bw2, ids2, passes2 = guard(T.from_numpy(X2).cuda())
     finally:
         ops.ms_set_variant("auto")
+        ops.MS_SPARSE = "auto"
     assert passes == int(g["passes"]) and passes2 == int(g["r_passes"])
     np.testing.assert_allclose(bw, float(g["bw"]), rtol=1e-3)            # the embedding itself carries ~5e-4 of graph-tie noise
     np.testing.assert_allclose(bw2, float(g["r_bw"]), rtol=2e-5)

@@ -39,12 +39,18 @@ def test_bandwidth_matches_golden_and_oracle(T, golden):
 def variant(request):
     """Force one of the two d = 128 iteration kernels for the test, restore the size-based choice after."""
     from sednet_hip import ops
-    ops.ms_set_variant(request.param)
+    if request.param == "sparse":            # the block-sparse split-fp16 schedule, forced (default: chosen per cloud)
+        ops.ms_set_variant("auto")
+        ops.MS_SPARSE = "on"
+    else:
+        ops.ms_set_variant(request.param)
     yield request.param
     ops.ms_set_variant("auto")
+    ops.MS_SPARSE = "auto"
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c"], indirect=True)
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c", "sparse"],
+                         indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
     from src.mean_shift import MeanShift
@@ -188,7 +194,7 @@ def test_chunked_schedule_other_widths(T):
 
 
 def test_block_sparse_schedule(T):
-    """Opt-in sparse schedule (rows sorted by nearest pivot, blocks with all weights <= e^-30 skipped): same rows in the
+    """Block-sparse schedule (rows sorted by nearest pivot, blocks with all weights <= e^-30 skipped): same rows in the
     caller's order within summation-order noise, identical labels; nothing to skip on unstructured data; argument checks."""
     from sednet_hip import ops, synth
     from sednet_hip._lib import lib, ptr, stream
@@ -197,31 +203,55 @@ def test_block_sparse_schedule(T):
                    for c in range(3)])
     X = dev(T, Xs)
     bw = ops.ms_bandwidth(X, 150, 0.003)
-    dense = ops.ms_iterate(X, bw, 50)
-    for bounds in (False, True):
-        sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0, bounds=bounds)
-        np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5)
+    dense = ops._ms_iterate_dense(X, bw, 50)
+    for bounds, f16 in ((False, False), (True, False), (True, True)):
+        sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0, bounds=bounds, f16=f16)
+        np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5 if not f16 else 3e-6)
+    # the split-fp16 sparse kernel counts what it visits: a small share of the dense schedule on clustered rows
+    stats = T.zeros(4, dtype=T.int64, device="cuda")
+    ops.ms_iterate_sparse(X, bw, 50, -30.0, stats=stats)
+    st = stats.cpu().numpy().astype(np.float64)
+    assert st[3] == 3 * 39 * 8 * 312 * 50 and st[1] / st[3] < 0.25 and st[2] <= st[1]
     order = ops.ms_pivot_order(X)[0]
     assert (T.sort(order, 1)[0] == T.arange(9973, device="cuda")[None]).all()          # a permutation per cloud
+    # "auto" (the default) picks the sparse schedule for these clouds and the dense one for unstructured rows, per cloud
     ms = MeanShift()
-    ref = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
     try:
-        ops.MS_SPARSE_SKIP = -30.0
+        ops.MS_SPARSE = "off"
+        ref = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
+        ops.MS_SPARSE = "auto"
+        ops.MS_SPARSE_STATS.update(sparse_clouds=0, dense_clouds=0)
         got = ms.guard_mean_shift_batch(X, 0.015, 50)[0].cpu().numpy()
+        assert ops.MS_SPARSE_STATS["sparse_clouds"] >= 3 and ops.MS_SPARSE_STATS["dense_clouds"] == 0
+        Xm = T.cat([X[:1], T.nn.functional.normalize(T.randn(1, 9973, 128, generator=T.Generator().manual_seed(2)), dim=2).cuda(),
+                    X[1:2]])
+        bwm = ops.ms_bandwidth(Xm, 150, 0.003)
+        ops.MS_SPARSE_STATS.update(sparse_clouds=0, dense_clouds=0)
+        mixed = ops.ms_iterate(Xm, bwm, 50)
+        assert ops.MS_SPARSE_STATS == {"sparse_clouds": 2, "dense_clouds": 1}
+        # the decision is per cloud: a clustered cloud of a mixed batch gets exactly the rows it gets alone (the dense
+        # schedules sum in an order that depends on how many clouds share the launch: chunked for one, batched for many)
+        for c in range(3):
+            alone = ops.ms_iterate(Xm[c:c + 1], bwm[c:c + 1], 50)[0].cpu().numpy()
+            if c == 1:
+                np.testing.assert_allclose(mixed[c].cpu().numpy(), alone, atol=2e-5)
+            else:
+                np.testing.assert_array_equal(mixed[c].cpu().numpy(), alone)
     finally:
-        ops.MS_SPARSE_SKIP = None
+        ops.MS_SPARSE = "auto"
     for b in range(3):
         np.testing.assert_array_equal(canon(got[b]), canon(ref[b]))
     # wider clusters (sigma = 0.04: neighbouring clusters overlap in angle, few blocks can be skipped) -- still the same rows
     Xw = dev(T, np.stack([synth.clustered_embedding(N=5000, d=128, n_clusters=20, sigma=0.04, seed=77)[0]]))
     bww = ops.ms_bandwidth(Xw, 75, 0.003)
-    np.testing.assert_allclose(ops.ms_iterate_sparse(Xw, bww, 50, -30.0).cpu().numpy(),
-                               ops.ms_iterate(Xw, bww, 50).cpu().numpy(), atol=3e-5)
+    for f16 in (False, True):
+        np.testing.assert_allclose(ops.ms_iterate_sparse(Xw, bww, 50, -30.0, f16=f16).cpu().numpy(),
+                                   ops._ms_iterate_dense(Xw, bww, 50).cpu().numpy(), atol=3e-5)
     Xr = T.nn.functional.normalize(T.randn(2, 3000, 128, generator=T.Generator().manual_seed(1)), dim=2).cuda()
     bwr = ops.ms_bandwidth(Xr, 45, 0.003)
-    for bounds in (False, True):
-        np.testing.assert_allclose(ops.ms_iterate_sparse(Xr, bwr, 5, bounds=bounds).cpu().numpy(),
-                                   ops.ms_iterate(Xr, bwr, 5).cpu().numpy(), atol=2e-5)
+    for bounds, f16 in ((False, False), (True, False), (True, True)):
+        np.testing.assert_allclose(ops.ms_iterate_sparse(Xr, bwr, 5, bounds=bounds, f16=f16).cpu().numpy(),
+                                   ops._ms_iterate_dense(Xr, bwr, 5).cpu().numpy(), atol=2e-5)
     out = T.empty_like(Xr)
     assert lib.sed_ms_iterate_sparse_f32(2, 3000, 128, 5, ptr(bwr), ptr(Xr), ptr(out), 0.0, stream()) == -1
     X64 = T.zeros(1, 64, 64, device="cuda")

@@ -13,13 +13,13 @@ m_type, m_inst = bench.build_models(20, torch.device("cuda"))
 pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50)
 res = {}
 for mode in (None, -30.0):
-    ops.MS_SPARSE_SKIP = mode
+    ops.MS_SPARSE = "on" if mode else "off"
     out = pipe(x); torch.cuda.synchronize()
     t0 = time.perf_counter(); out = pipe(x); torch.cuda.synchronize()
     res[mode] = (time.perf_counter() - t0, out["labels"].cpu().numpy(), out["n_labels"])
     print("sparse" if mode else "dense ", f"{res[mode][0] * 1e3:.1f} ms per step, {B / res[mode][0]:.1f} clouds/s, clusters per cloud",
           np.asarray(out["n_labels"].cpu() if hasattr(out["n_labels"], "cpu") else out["n_labels"])[:8])
-ops.MS_SPARSE_SKIP = None
+ops.MS_SPARSE = "auto"
 def canonical_labels(l):                       # relabel by first occurrence
     _, first, inv = np.unique(l, return_index=True, return_inverse=True)
     return np.argsort(np.argsort(first))[inv]

@@ -75,10 +75,11 @@ int sed_csr_spmm_f32(int B, int N, int ncol, size_t nnz_stride, const int* rowpt
 /* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */
 int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, float* bw, sed_stream_t stream);
 /* K-th smallest (1-based, self included) of 2 - 2 x_i.x_j per row WITHOUT the N x N matrix (two MFMA sweeps + short
- * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128}, K <= sed_ms_kth_fused_max_k().
+ * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128}, K <= sed_ms_kth_fused_max_k(N)
+ * (160; 224 on clouds of >= 4096 points, where the first sweep samples every other key tile).
  * *overflow (device int) becomes 1 if a candidate list overflowed: kth is then invalid, use the materialised path.
  * src/mean_shift.py:115-137 (compute_bandwidth: dist = 2 - 2 X X^T, topk(K)). */
-int sed_ms_kth_fused_max_k(void);
+int sed_ms_kth_fused_max_k(int N);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
 int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
                          int* overflow, sed_stream_t stream);

@@ -7,7 +7,8 @@
 //   sweep 1: per query, the keys a lane sees fall into 32 buckets (2 lanes x 16 accumulator registers); every bucket
 //            keeps its M = 8 smallest distances. Those 256 values are distinct row elements, so their K-th smallest T
 //            bounds the row's K-th smallest from above (K <= 160). On clouds of >= 4096 points the sweep visits every
-//            other key tile (any 256 distinct elements give a valid bound).
+//            other key tile; for 160 < K <= 224 it looks up rank K / 2 + 3 sqrt(K) + 2 instead (the guard retries' quantiles
+//            0.018, 0.0216 at N = 10 000); sweep 2 verifies that at least K candidates were found.
 //   sweep 2: recomputes the distances (same instructions => same bits) and appends the ~2 K values <= T to lane-private
 //            lists (plain stores).
 //   finalize: one wave per query bisects its <= 512 candidates for the exact K-th smallest.
@@ -20,7 +21,19 @@ namespace {
 
 constexpr int BM = 8;             // minima kept per bucket in sweep 1
 constexpr int CAPK = 256;         // candidates per lane (two lanes per query)
-constexpr int KMAX = 160;
+constexpr int KMAX = 160;         // every key visited in sweep 1 (N < 4096)
+constexpr int KMAX_SAMPLED = 224; // sweep 1 on every other key tile (N >= 4096); beyond, the 8-deep buckets saturate
+
+// Rank looked up among the sweep-1 values. K <= 160: K itself -- the K-th smallest of ANY set of distinct row elements
+// bounds the row's K-th from above, sampled sweep or not (about 2 K candidates in sweep 2 when half the tiles were
+// visited). Larger K (sampled sweeps only; the guard retries' quantiles): the number of the row's K smallest that fall into
+// the sampled half is ~ Binomial(K, 1/2), so rank K / 2 + 3 sqrt(K) + 2 (six standard deviations above the mean) puts T
+// above the true K-th except with probability ~1e-9 per row -- or for rows whose nearest keys crowd into the unvisited
+// tiles. Sweep 2 counts what it finds: a row with fewer than K candidates raises the overflow flag (materialised path).
+__host__ __device__ inline int sweep1_rank(int K, bool sampled) {
+    if (!sampled || K <= KMAX) return K;
+    return (int)(0.5f * (float)K + 3.0f * sqrtf((float)K)) + 2;
+}
 
 // F16 (d = 64 / 128): split-fp16 dot products on the pre-split row image (split16.h), like knn_fused.hip.
 template <int NT, int PASS, bool F16>
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         for (int i = 0; i < BM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) bk[i][r] = bm[i][r] >= 3.0e38f ? 0xFFFFFFFFu : f32_sortable(bm[i][r]);
+        const int Ks = sweep1_rank(K, tstep == 2);
         uint32_t lo = 0, hiv = 0xFFFFFFFFu;
         for (int it = 0; it < 32; ++it) {
             const uint32_t mid = lo + ((hiv - lo) >> 1);
@@ -173,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c += bk[i][r] <= mid ? 1 : 0;
             c += __shfl_xor(c, 32, 64);
-            if (lo < hiv) { if (c >= K) hiv = mid; else lo = mid + 1; }
+            if (lo < hiv) { if (c >= Ks) hiv = mid; else lo = mid + 1; }
         }
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else if (qrow < N) {
         counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
-        if (cnt > CAPK) *overflow = 1;
+        if (cnt > CAPK || cnt + __shfl_xor(cnt, 32, 64) < K) *overflow = 1;      // list overflow / T below the K-th value
     }
 }
 
@@ -239,7 +253,8 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
 
 }  // namespace
 
-extern "C" int sed_ms_kth_fused_max_k(void) { return KMAX; }
+// largest K the fused path takes for clouds of N points
+extern "C" int sed_ms_kth_fused_max_k(int N) { return N >= 4096 ? KMAX_SAMPLED : KMAX; }
 
 extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
@@ -253,7 +268,7 @@ extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
 extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
                                     int* overflow, hipStream_t stream) {
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
-    if (d % 32 != 0 || d < 32 || d > 128 || K > KMAX) return SED_EUNSUPPORTED;
+    if (d % 32 != 0 || d < 32 || d > 128 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
     hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);

@@ -133,6 +133,9 @@ def knn_points_normals(x6, k, W=1.0):
 # mean-shift
 # ---------------------------------------------------------------------------------------------------
 
+KTH_FUSED_MIN_BLOCKS = 0        # the fused path wins at every batch size since its sweeps run split-fp16 (round 2)
+
+
 def ms_bandwidth(X, K, min_bw=0.003):
     """X [B,n,D] unit rows (padded) -> bw [B] = max(mean_i sqrt(max(K-th smallest of 2-2x_i.x_j, 1e-6)), min_bw)
     (src/mean_shift.py:115-137 and the clamp at :34)."""
@@ -142,9 +145,9 @@ def ms_bandwidth(X, K, min_bw=0.003):
     kth = torch.empty((B, N), dtype=torch.float32, device=X.device)
     bw = torch.empty((B,), dtype=torch.float32, device=X.device)
     done = False
-    # many clouds: two MFMA sweeps + candidate lists, no N x N matrix (bandwidth_fused.hip). A few clouds leave most CUs
-    # idle in the sweeps; there the materialised path below is the faster one.
-    if FUSED_KNN and D <= 128 and K <= lib.sed_ms_kth_fused_max_k() and B * ((N + 127) // 128) >= 512:
+    # two MFMA sweeps + candidate lists, no N x N matrix (bandwidth_fused.hip); the materialised path below is the
+    # fall-back (K beyond the fused kernel's range, candidate-list overflow)
+    if FUSED_KNN and D <= 128 and K <= lib.sed_ms_kth_fused_max_k(N) and B * ((N + 127) // 128) >= KTH_FUSED_MIN_BLOCKS:
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
         flag = torch.empty((1,), dtype=torch.int32, device=X.device)
@@ -171,13 +174,17 @@ MS_SPARSE_SKIP = -30.0
 MS_SPARSE_MAX_NEAR = 0.3
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
 _MS_VARIANT = "auto"
+_PROBE_IDX = {}
 
 
 def ms_near_fraction(X, bw, skip_below=-30.0, rows=64, keys=512):
     """[B] share of (sampled row, sampled key) pairs with exp(-dist / (2 b^2)) > e^skip_below, dist = 2 - 2 x.y."""
     B, N, D = X.shape
-    qi = torch.linspace(0, N - 1, min(rows, N), device=X.device).long()
-    ki = torch.linspace(0, N - 1, min(keys, N), device=X.device).long()
+    key = (N, rows, keys, str(X.device))
+    if key not in _PROBE_IDX:                # fixed pseudo-random rows (a strided sample aliases with periodic row orders)
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(12345))
+        _PROBE_IDX[key] = (perm[:min(rows, N)].to(X.device), perm[-min(keys, N):].to(X.device))
+    qi, ki = _PROBE_IDX[key]
     dist = 2.0 - 2.0 * torch.bmm(X[:, qi], X[:, ki].transpose(1, 2))
     thr = (-2.0 * skip_below) * bw * bw
     return (dist < thr.view(B, 1, 1)).float().mean((1, 2))
@@ -219,20 +226,14 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P))
 
 
-def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3, f16=True, stats=None):
-    """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
-    are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
-    caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
-    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
-    f16 (with bounds): products on the fp16 matrix pipe (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional
-    int64 [4] device tensor the kernel adds its visit counts to."""
+def ms_sparse_prepare(X, n_pivots=64, bounds=True):
+    """Sorted rows + the geometric side tables of the block-sparse kernels (functions of X alone: reusable across the
+    guard retries of one embedding). -> dict."""
     B, N, D = X.shape
     order, piv, sdots = ms_pivot_order(X, n_pivots)
     gidx = order.unsqueeze(-1).expand(B, N, D)
-    Xs = torch.gather(X, 1, gidx).contiguous()
-    outs = torch.empty_like(Xs)
-    use_bounds = bounds and N <= 16384
-    if use_bounds:
+    prep = {"gidx": gidx, "Xs": torch.gather(X, 1, gidx).contiguous(), "bounds": bounds and N <= 16384}
+    if prep["bounds"]:
         P = piv.shape[1]
         ntile = (N + 31) // 32
         pad = ntile * 32 - N
@@ -241,32 +242,48 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, 
             sd = torch.nn.functional.pad(sd, (0, 0, 0, pad), value=1.0)
         worst = sd.view(B, ntile, 32, P).min(2)[0]                           # per tile and pivot: its farthest row
         best, rp = worst.max(2)                                               # reference pivot = tightest cap over the tile
-        alpha = torch.acos(best).contiguous()
-        pang = torch.acos(torch.bmm(piv, piv.transpose(1, 2)).clamp(-1.0, 1.0)).contiguous()
-        rp32 = rp.int().contiguous()
-        rowp = sdots.argmax(2).int().contiguous()                             # nearest pivot of every (sorted) row
+        prep.update(P=P, piv=piv, alpha=torch.acos(best).contiguous(), rp=rp.int().contiguous(),
+                    pang=torch.acos(torch.bmm(piv, piv.transpose(1, 2)).clamp(-1.0, 1.0)).contiguous(),
+                    rowp=sdots.argmax(2).int().contiguous())                  # nearest pivot of every (sorted) row
+    return prep
+
+
+def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, f16=True, stats=None):
+    Xs = prep["Xs"]
+    B, N, D = Xs.shape
+    outs = torch.empty_like(Xs)
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if use_bounds and f16:
-        nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
-        ws = torch.empty((nws,), dtype=torch.uint8, device=X.device)
-        check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                                ptr(rowp), ptr(rp32), ptr(alpha), ptr(piv), ptr(pang), P, float(margin),
-                                                ptr(ws), nws, ptr(stats) if stats is not None else None, stream()),
-              "ms_iterate_bounds_f16")
-    elif use_bounds:
-        check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                            ptr(rowp), ptr(rp32), ptr(alpha), ptr(piv), ptr(pang), P, float(margin),
-                                            stream()),
-              "ms_iterate_bounds")
+    if prep["bounds"]:
+        args = (ptr(prep["rowp"]), ptr(prep["rp"]), ptr(prep["alpha"]), ptr(prep["piv"]), ptr(prep["pang"]), prep["P"],
+                float(margin))
+        if f16:
+            nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
+            ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
+            check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                                    *args, ptr(ws), nws, ptr(stats) if stats is not None else None,
+                                                    stream()), "ms_iterate_bounds_f16")
+        else:
+            check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below), *args,
+                                                stream()), "ms_iterate_bounds")
     else:
         check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
                                             stream()), "ms_iterate_sparse")
     if TIMERS is not None:
         ev1.record()
         TIMERS.append(("ms_iterate_sparse", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
-    return torch.empty_like(outs).scatter_(1, gidx, outs)
+    return torch.empty_like(outs).scatter_(1, prep["gidx"], outs)
+
+
+def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3, f16=True, stats=None):
+    """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
+    are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
+    caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
+    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
+    f16 (with bounds): products on the fp16 matrix pipe (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional
+    int64 [4] device tensor the kernel adds its visit counts to."""
+    return ms_sparse_run(ms_sparse_prepare(X, n_pivots, bounds), bw, iters, skip_below, margin, f16, stats)
 
 
 def ms_iterate(X, bw, iters):

@@ -77,7 +77,8 @@ int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, 
 /* K-th smallest (1-based, self included) of 2 - 2 x_i.x_j per row WITHOUT the N x N matrix (two MFMA sweeps + short
  * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128}, K <= sed_ms_kth_fused_max_k(N)
  * (160; 224 on clouds of >= 4096 points, where the first sweep samples every other key tile).
- * *overflow (device int) becomes 1 if a candidate list overflowed: kth is then invalid, use the materialised path.
+ * overflow [B] (device ints): overflow[b] becomes 1 if a candidate list of cloud b overflowed: kth[b] is then invalid, use
+ * the materialised path for that cloud.
  * src/mean_shift.py:115-137 (compute_bandwidth: dist = 2 - 2 X X^T, topk(K)). */
 int sed_ms_kth_fused_max_k(int N);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
@@ -112,15 +113,21 @@ int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, c
 int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                               float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
                               const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
-/* The same block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel):
- * contract of sed_ms_iterate_bounds_f32 + a workspace (stage images of the sorted rows) and optional statistics -- 4 device
- * uint64 counters that are ADDED to: stage visits of workgroups, first products of waves, second products of waves, and
- * stages x iterations per wave (the dense count). Clouds whose rows are not unit vectors run the exact dense fp32 kernel. */
+/* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel). X: unit rows
+ * sorted so that 32-row tiles are cluster-pure (any order is correct; the order decides how much is skipped). Every tile t
+ * has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
+ * split) -- stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128], nref = sed_ms_iterate_bounds_f16_refs(N),
+ * unused rows zero; tile_cosalpha [B, nref]: the smallest dot product of a row of the group with its reference. Every
+ * iteration every wave measures its 32 queries against all references on the matrix pipe and skips the blocks with
+ * angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for all its queries and both references. workspace: stage
+ * images of rows and references; stats: NULL or 4 device uint64 counters that are ADDED to (stage visits of workgroups,
+ * first products of waves, second products of waves, stages x iterations per wave = the dense count). Clouds whose rows
+ * are not unit vectors run the exact dense fp32 kernel. N <= 16 384. */
+int sed_ms_iterate_bounds_f16_refs(int N);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
 int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                                  float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
-                                  const float* piv, const float* pang, int P, float margin, void* workspace,
-                                  size_t workspace_bytes, void* stats, sed_stream_t stream);
+                                  float skip_below, const float* tile_ref, const float* tile_cosalpha, float margin,
+                                  void* workspace, size_t workspace_bytes, void* stats, sed_stream_t stream);
 /* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
  * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
  * variant above), and split-fp16 (ms_iterate_f16.hip: the two fp32 products evaluated as 3 fp16 MFMAs each on round-to-

@@ -13,7 +13,8 @@
 //            lists (plain stores).
 //   finalize: one wave per query bisects its <= 512 candidates for the exact K-th smallest.
 // Distances are 2 - 2 s with s the same fp32 MFMA chain as pair_dist_kernel<NT, MODE_MS>, so the K-th values are
-// bit-identical to the materialised path. A list overflow raises a flag and the caller re-runs the materialised path.
+// bit-identical to the materialised path. A list overflow raises the cloud's flag and the caller re-runs that cloud on the
+// materialised path.
 #include "common.h"
 #include "split16.h"
 
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else if (qrow < N) {
         counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
-        if (cnt > CAPK || cnt + __shfl_xor(cnt, 32, 64) < K) *overflow = 1;      // list overflow / T below the K-th value
+        if (cnt > CAPK || cnt + __shfl_xor(cnt, 32, 64) < K) overflow[cloud] = 1;   // list overflow / T below the K-th value
     }
 }
 
@@ -263,15 +264,16 @@ extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
 }
 
 // X [B,N,d] unit rows, d in {32, 64, 96, 128} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
-// over j, bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32. *overflow (device int, zeroed here) becomes 1 if a
-// candidate list overflowed: kth is then invalid and the caller must use the materialised path.
+// over j, bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32. overflow [B] (device ints, zeroed here): overflow[b]
+// becomes 1 if a candidate list of cloud b overflowed (or its threshold fell short): kth[b] is then invalid and the caller
+// must use the materialised path for that cloud.
 extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
                                     int* overflow, hipStream_t stream) {
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 128 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
-    hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
+    hipError_t e = hipMemsetAsync(overflow, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     switch (d / 32) {
         case 1: launch_kth<1>(B, X, w, N, K, overflow, stream); break;

@@ -838,9 +838,8 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
-                         int** flags_out, float skip_below, const int* row_piv, const int* tile_rp,
-                         const float* tile_alpha, const float* piv, const float* pang, int P, float margin,
-                         unsigned long long* stats, hipStream_t stream);
+                         int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                         float margin, unsigned long long* stats, hipStream_t stream);
 
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
                              hipStream_t stream) {
@@ -996,29 +995,34 @@ extern "C" int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const f
 }
 
 // ---- block-sparse split-fp16 schedule (ms_iterate_f16.hip: ms_iterate_d128_f16s_kernel) ------------------------------
-// Contract of sed_ms_iterate_bounds_f32 (ms_sparse.hip: rows sorted into cluster-pure 32-row tiles + the pivot side
-// tables) with the products on the fp16 matrix pipe; workspace = sed_ms_iterate_bounds_f16_workspace_bytes(B, N);
+// X [B,N,128]: unit rows sorted so that 32-row tiles are cluster-pure (any order is CORRECT; the order decides how much can
+// be skipped); every tile t has two unit reference vectors (normalised means of two groups of its rows -- the rows before
+// and after a cluster border, or any split), stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128],
+// nref = sed_ms_iterate_bounds_f16_refs(N) (unused rows zero); tile_cosalpha [B, nref]: the smallest dot product between a
+// row of the group and its reference. A 32 x 32 block is skipped when every query of the wave satisfies
+// angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for both references (=> all its weights <= e^skip_below). workspace = sed_ms_iterate_bounds_f16_workspace_bytes(B, N);
 // stats: NULL or 4 device uint64 counters that are ADDED to (workgroup stage visits, wave first products, wave second
 // products, stages x iterations per wave = the dense count). Clouds whose rows are not unit vectors run the exact dense
-// fp32 kernel instead (same flag as the dense split-fp16 schedule).
+// fp32 kernel instead (same flag as the dense split-fp16 schedule). N <= 16 384, d = 128.
+extern "C" int sed_ms_iterate_bounds_f16_refs(int N) { return N > 0 ? 2 * ((((N + 31) / 32) + 31) / 32) * 32 : 0; }
+
 extern "C" size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
     return ms_f16_sparse_workspace_bytes(B, N);
 }
 
 extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X,
-                                             float* newX, float skip_below, const int* row_piv, const int* tile_rp,
-                                             const float* tile_alpha, const float* piv, const float* pang, int P,
-                                             float margin, void* workspace, size_t workspace_bytes, void* stats,
-                                             hipStream_t stream) {
-    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !row_piv || !tile_rp ||
-        !tile_alpha || !piv || !pang || P <= 0 || margin < 0.f || !workspace)
+                                             float* newX, float skip_below, const float* tile_ref,
+                                             const float* tile_cosalpha, float margin, void* workspace,
+                                             size_t workspace_bytes, void* stats, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !tile_ref || !tile_cosalpha ||
+        margin < 0.f || !workspace)
         return SED_EINVAL;
     if (d != 128) return SED_EUNSUPPORTED;
     if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
     int* flags = nullptr;
-    const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, row_piv, tile_rp,
-                                        tile_alpha, piv, pang, P, margin, (unsigned long long*)stats, stream);
+    const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
+                                        margin, (unsigned long long*)stats, stream);
     if (rc != SED_OK) return rc;
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
     static bool attr_fb = false;

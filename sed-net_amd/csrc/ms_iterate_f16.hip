@@ -563,28 +563,36 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 
 // ------------------------------------------------------------------------------------------------------------
 // Block-sparse schedule on the pipelined split-fp16 kernel (round 2; the fp32 version is ms_sparse.hip).
-// Rows arrive sorted so that every 32-row tile -- here: every stage image -- is cluster-pure, with the geometric side
-// tables of sed_ms_iterate_bounds_f32 (nearest pivot of every row, reference pivot + cap angle alpha of every tile,
-// pivot-pivot angles). Every iteration
-//   (1) a query row measures beta = its current angle to its own pivot (fp32, from the split registers);
-//   (2) every wave marks the stages it needs: angle(P_row, P_tile) - beta - alpha_tile < theta, theta = the angle at which the
-//       kernel weight drops to e^skip (triangle inequality on the unit sphere: everything else carries weights <= e^skip);
+// Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure, together with two unit reference
+// vectors per tile (normalised means of two groups of its rows) and cos(alpha) of each, alpha = the widest angle between
+// the reference and a row of its group. Every iteration
+//   (1) every wave measures its 32 current queries against ALL tile references: S = M Q^T on the matrix pipe (fp16 head
+//       parts only: |error| <= 5e-4 in the dot product, covered by the threshold's slack), 8 MFMAs per 32 references;
+//   (2) it marks the stages it needs: by the triangle inequality on the unit sphere angle(q, x) >= angle(q, m) - alpha for
+//       every key x within alpha of a reference m, so a tile all of whose rows lie in caps with
+//       q . m <= cos(theta + alpha + margin) - slack  for all 32 queries carries only weights <= e^skip for them (theta = the
+//       angle at which the kernel weight drops to e^skip). A tile has TWO references, each covering a part of its rows: the
+//       tile at the border between two clusters of the sorted order would otherwise be wide open and needed by everybody;
 //   (3) the workgroup compacts the union of its 8 waves' marks into a stage list (thread s owns stage s: nst <= 512);
 //   (4) the pipeline of ms_iterate_d128_f16p_kernel runs over that list only -- stages nobody needs are never copied to
 //       LDS; a wave that does not need a listed stage only takes part in its barrier; a wave whose weights of a stage all
 //       round to zero in fp16 (p 2^14 <= 2^-25: exactly the blocks whose O-contribution is 0 in the dense kernel too)
 //       skips the second product.
+// The references are staged like keys: ms_split_kernel lays M out as stage images (32 references per image), and (1)
+// copies the head planes of up to 12 images at a time into the (then idle) stage buffers.
 // The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
 // direction so that an iteration starts on the stages the previous one left in L2.
 // What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
 constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
 
+constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
+constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
+
 template <bool STAGGER>
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
-    const int* __restrict__ row_piv, const int* __restrict__ tile_rp, const float* __restrict__ tile_alpha,
-    const float* __restrict__ piv, const float* __restrict__ pang, int P, float margin,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
     unsigned long long* __restrict__ stats) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     __shared__ unsigned long long wmask[8][MAXW];
     __shared__ int slist[512];
     __shared__ int wcount[8];
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
@@ -603,7 +612,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     if (flags[cloud]) return;
     const float* Xc = X + (size_t)cloud * N * 128;
     const int nst = (N + 31) >> 5;
-    const int nword = (nst + 63) >> 6;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
     const int qrow = bx * 256 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
@@ -613,13 +623,20 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
     const float K0 = LOG2_SCALE_P - inv_b2_l2e;
     const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
-    const float Dthr = -2.0f * skip_below * b * b;       // dist >= Dthr  <=>  weight <= e^skip
-    const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin : 1.0e9f;     // 1e9: never skip
-    const int* rpc = tile_rp + (size_t)cloud * nst;
-    const float* alc = tile_alpha + (size_t)cloud * nst;
-    const int myp = row_piv[(size_t)cloud * N + qrow_c];
-    const float* mypiv = piv + ((size_t)cloud * P + myp) * 128;
-
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + rho], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
     h16x8 qh[8], ql[8];
     auto split_q = [&](int ks, const float* v) {
 #pragma unroll
@@ -684,45 +701,43 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     unsigned long long n_listed = 0, n_first = 0, n_second = 0;      // per-wave counts (statistics only)
 
     for (int it = 0; it < iters; ++it) {
-        // ---- (1) beta: this row's angle to its pivot
-        float dp = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 pv = *(const f32x4*)(mypiv + 16 * ks + 8 * g + 4 * hi);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    dp = fmaf((float)qh[ks][4 * g + u] + (float)ql[ks][4 * g + u], pv[u], dp);
+        // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
+        for (int g0 = 0; g0 < nrs; g0 += F16S_REFGROUP) {
+            const int ng = min(F16S_REFGROUP, nrs - g0);
+            if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
+            for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
+                const int im = pc / 9, piece = pc - 9 * im;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                    (__attribute__((address_space(3))) void*)(lds + im * F16S_REFBYTES + piece * 1024), 16, 0, 0);
             }
-        dp *= UNSCALE_Q;
-        dp += xor32(dp);
-        const float beta_i = qrow < N ? acosf(fminf(fmaxf(dp, -1.0f), 1.0f)) : -1.0e9f;
-        // ---- (2) this wave's stage mask: one pass per DISTINCT pivot among its rows, stages across lanes
-        if (lane < MAXW) wmask[wave][lane] = 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(qrow < N);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const int a = __builtin_amdgcn_readlane(myp, leader);
-            const bool mine = myp == a && qrow < N;
-            float beta = mine ? beta_i : -1.0e9f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int im = 0; im < ng; ++im) {
+                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff;
+                f32x16 sr;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) beta = fmaxf(beta, __shfl_xor(beta, off, 64));
-            const float* ang = pang + ((size_t)cloud * P + a) * P;
-            unsigned long long mw[MAXW];
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
 #pragma unroll
-            for (int w = 0; w < MAXW; ++w) {
-                const int t = w * 64 + lane;
-                bool need = false;
-                if (w < nword && t < nst) need = !(ang[rpc[t]] - beta - alc[t] >= theta);
-                mw[w] = __builtin_amdgcn_ballot_w64(need);
+                for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                unsigned word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * g + u] > th[u]);
+                        word |= ((unsigned)bal != 0u ? 1u : 0u) << (8 * g + u);              // tile row of lane half 0
+                        word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << (8 * g + u + 4);  // ... of lane half 1
+                    }
+                }
+                if (lane == 0) {                                  // a tile is needed if either of its references is near
+                    unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                    *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                }
             }
-#pragma unroll
-            for (int w = 0; w < MAXW; ++w)
-                if (lane == w) wmask[wave][w] |= mw[w];
-            todo &= ~__builtin_amdgcn_ballot_w64(mine);
         }
+        if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
         __syncthreads();
         // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
         int ns;
@@ -1018,21 +1033,28 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
 }
 
 
+static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
+
+// stage images of the sorted rows | flags | stage images of the tile references | scratch flags
 size_t ms_f16_sparse_workspace_bytes(int B, int N) {
-    return f16_blob_bytes(B, N, 0) + (((size_t)B * sizeof(int) + 255) / 256) * 256;
+    const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
+    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 2 * f16_flag_bytes(B);
 }
 
-// Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles (side tables as sed_ms_iterate_bounds_f32).
+// Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
+// row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
+// tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 4 x u64, accumulated).
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
-                         int** flags_out, float skip_below, const int* row_piv, const int* tile_rp,
-                         const float* tile_alpha, const float* piv, const float* pang, int P, float margin,
-                         unsigned long long* stats, hipStream_t stream) {
+                         int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                         float margin, unsigned long long* stats, hipStream_t stream) {
     using L = StageLayout<32>;
-    const int nst = (N + 31) / 32;
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
+    uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
+    int* flags2 = (int*)(refblob + f16_blob_bytes(B, nrs * 32, 0));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
@@ -1046,8 +1068,9 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     ms_iterate_d128_f16s_kernel<true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
-        X, blob, newX, bw, flags, N, iters, skip_below, row_piv, tile_rp, tile_alpha, piv, pang, P, margin, stats);
+        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

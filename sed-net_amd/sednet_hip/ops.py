@@ -144,23 +144,30 @@ def ms_bandwidth(X, K, min_bw=0.003):
         raise RuntimeError(f"selected index k out of range (K={K}, rows={N})")   # torch.topk's error in the reference
     kth = torch.empty((B, N), dtype=torch.float32, device=X.device)
     bw = torch.empty((B,), dtype=torch.float32, device=X.device)
-    done = False
+    todo = None                                              # clouds left for the materialised path (None: all)
     # two MFMA sweeps + candidate lists, no N x N matrix (bandwidth_fused.hip); the materialised path below is the
-    # fall-back (K beyond the fused kernel's range, candidate-list overflow)
+    # fall-back (K beyond the fused kernel's range, clouds whose candidate lists overflowed)
     if FUSED_KNN and D <= 128 and K <= lib.sed_ms_kth_fused_max_k(N) and B * ((N + 127) // 128) >= KTH_FUSED_MIN_BLOCKS:
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
-        flag = torch.empty((1,), dtype=torch.int32, device=X.device)
+        flag = torch.empty((B,), dtype=torch.int32, device=X.device)
         check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), stream()), "ms_kth_fused")
-        done = int(flag.item()) == 0
-        FUSED_STATS["fused" if done else "fallback"] += 1
-    if not done:
-        chunks, step = _cloud_chunks(B, N)
+        todo = torch.nonzero(flag.cpu()).squeeze(1)         # one small D->H copy
+        FUSED_STATS["fused"] += B - todo.numel()
+        FUSED_STATS["fallback"] += todo.numel()
+        del ws
+    if todo is None or todo.numel():
+        Xm = X if todo is None else X[todo.to(X.device)].contiguous()
+        Bm = Xm.shape[0]
+        kth_m = kth if todo is None else torch.empty((Bm, N), dtype=torch.float32, device=X.device)
+        chunks, step = _cloud_chunks(Bm, N)
         ws = _pair_ws(step, N, X.device)
         for b0, b1 in chunks:
             nb = b1 - b0
-            check(lib.sed_pairdist_ms_f32(nb, N, D, ptr(X[b0:b1]), ptr(ws), _ld(N), stream()), "pairdist_ms")
-            check(lib.sed_row_kth_f32(nb, N, _ld(N), K, ptr(ws), ptr(kth[b0:b1]), stream()), "row_kth")
+            check(lib.sed_pairdist_ms_f32(nb, N, D, ptr(Xm[b0:b1]), ptr(ws), _ld(N), stream()), "pairdist_ms")
+            check(lib.sed_row_kth_f32(nb, N, _ld(N), K, ptr(ws), ptr(kth_m[b0:b1]), stream()), "row_kth")
+        if todo is not None:
+            kth[todo.to(X.device)] = kth_m
     check(lib.sed_ms_bandwidth_finalize_f32(B, N, float(min_bw), ptr(kth), ptr(bw), stream()), "bandwidth_finalize")
     return bw
 
@@ -194,7 +201,8 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     """Row order that makes 32-row blocks cluster-pure. Every row joins its nearest of `n_pivots` farthest-point pivot
     rows (largest dot product on the unit sphere); pivots closer than `merge_angle` (single linkage) form a super-group, and
     rows are stable-sorted by (super-group, pivot) so that the pivot groups of one cluster are adjacent.
-    -> (order [B,N] int64, pivots [B,P,D], dots of the SORTED rows with all pivots [B,N,P])."""
+    -> (order [B,N] int64, pivots [B,P,D], dots of the SORTED rows with all pivots [B,N,P], super-group of the sorted
+    rows [B,N])."""
     B, N, D = X.shape
     P = min(n_pivots, N)
     # farthest-point pivots (greedy k-centre on the sphere): every cluster gets at least one pivot as long as there are
@@ -222,21 +230,51 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
         reach = (torch.bmm(reach, reach) > 0).float()
     comp = torch.where(reach > 0, torch.arange(P, device=X.device).view(1, 1, P), P).min(2)[0]     # [B,P] min member
     key = torch.gather(comp, 1, grp) * P + grp
-    order = torch.sort(key, dim=1, stable=True)[1]
-    return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P))
+    skey, order = torch.sort(key, dim=1, stable=True)
+    return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P)), skey // P
 
 
-def ms_sparse_prepare(X, n_pivots=64, bounds=True):
-    """Sorted rows + the geometric side tables of the block-sparse kernels (functions of X alone: reusable across the
-    guard retries of one embedding). -> dict."""
+def ms_sparse_prepare(X, n_pivots=64, bounds=True, f16=True):
+    """Sorted rows + the geometric side tables of the block-sparse kernels (functions of X alone). -> dict.
+    f16 kernel: per 32-row tile its normalised mean and the smallest dot product of a row with it; fp32 bounds kernel:
+    the pivot tables of sed_ms_iterate_bounds_f32."""
     B, N, D = X.shape
-    order, piv, sdots = ms_pivot_order(X, n_pivots)
+    order, piv, sdots, comp = ms_pivot_order(X, n_pivots)
     gidx = order.unsqueeze(-1).expand(B, N, D)
-    prep = {"gidx": gidx, "Xs": torch.gather(X, 1, gidx).contiguous(), "bounds": bounds and N <= 16384}
-    if prep["bounds"]:
+    Xs = torch.gather(X, 1, gidx).contiguous()
+    prep = {"gidx": gidx, "Xs": Xs, "bounds": bounds and N <= 16384, "f16": f16}
+    if not prep["bounds"]:
+        return prep
+    ntile = (N + 31) // 32
+    pad = ntile * 32 - N
+    if f16:
+        # two references per tile: the rows of the tile's first super-group and the rest (a tile inside one cluster: its two
+        # halves), so that the tile at the border between two clusters is covered by two narrow caps instead of a wide one
+        if pad:                                                               # pad with copies of the last row
+            Xs_p = torch.cat([Xs, Xs[:, -1:].expand(B, pad, D)], 1)
+            comp = torch.cat([comp, comp[:, -1:].expand(B, pad)], 1)
+        else:
+            Xs_p = Xs
+        Xt = Xs_p.view(B, ntile, 32, D)
+        ct = comp.view(B, ntile, 32)
+        first = ct == ct[:, :, :1]
+        pure = first.all(2, keepdim=True)
+        half = (torch.arange(32, device=X.device) < 16).view(1, 1, 32)
+        ga = torch.where(pure, half, first)                                   # group of reference 0; reference 1: the rest
+        nref = lib.sed_ms_iterate_bounds_f16_refs(N)
+        ref = torch.zeros((B, nref, D), dtype=torch.float32, device=X.device)
+        cosalpha = torch.ones((B, nref), dtype=torch.float32, device=X.device)
+        t = torch.arange(ntile, device=X.device)
+        for w, g in enumerate((ga, ~ga)):
+            gf = g.unsqueeze(-1).float()
+            m = torch.nn.functional.normalize((Xt * gf).sum(2), dim=2)
+            dots = (Xt * m.unsqueeze(2)).sum(3)
+            rho = ((t // 32) * 2 + w) * 32 + t % 32
+            ref[:, rho] = m
+            cosalpha[:, rho] = torch.where(g, dots, torch.ones_like(dots)).min(2)[0]
+        prep.update(ref=ref, cosalpha=cosalpha)
+    else:
         P = piv.shape[1]
-        ntile = (N + 31) // 32
-        pad = ntile * 32 - N
         sd = sdots.clamp(-1.0, 1.0)
         if pad:
             sd = torch.nn.functional.pad(sd, (0, 0, 0, pad), value=1.0)
@@ -248,25 +286,24 @@ def ms_sparse_prepare(X, n_pivots=64, bounds=True):
     return prep
 
 
-def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, f16=True, stats=None):
+def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
     Xs = prep["Xs"]
     B, N, D = Xs.shape
     outs = torch.empty_like(Xs)
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if prep["bounds"]:
-        args = (ptr(prep["rowp"]), ptr(prep["rp"]), ptr(prep["alpha"]), ptr(prep["piv"]), ptr(prep["pang"]), prep["P"],
-                float(margin))
-        if f16:
-            nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
-            ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
-            check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                                    *args, ptr(ws), nws, ptr(stats) if stats is not None else None,
-                                                    stream()), "ms_iterate_bounds_f16")
-        else:
-            check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below), *args,
-                                                stream()), "ms_iterate_bounds")
+    if prep["bounds"] and prep["f16"]:
+        nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
+        check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                                ptr(prep["ref"]), ptr(prep["cosalpha"]), float(margin), ptr(ws), nws,
+                                                ptr(stats) if stats is not None else None, stream()),
+              "ms_iterate_bounds_f16")
+    elif prep["bounds"]:
+        check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                            ptr(prep["rowp"]), ptr(prep["rp"]), ptr(prep["alpha"]), ptr(prep["piv"]),
+                                            ptr(prep["pang"]), prep["P"], float(margin), stream()), "ms_iterate_bounds")
     else:
         check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
                                             stream()), "ms_iterate_sparse")
@@ -281,9 +318,10 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, 
     are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
     caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
     bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
-    f16 (with bounds): products on the fp16 matrix pipe (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional
-    int64 [4] device tensor the kernel adds its visit counts to."""
-    return ms_sparse_run(ms_sparse_prepare(X, n_pivots, bounds), bw, iters, skip_below, margin, f16, stats)
+    f16 (with bounds): products on the fp16 matrix pipe and bounds from the exact angle of every query to every tile's
+    mean (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional int64 [4] device tensor the kernel adds its visit
+    counts to."""
+    return ms_sparse_run(ms_sparse_prepare(X, n_pivots, bounds, f16), bw, iters, skip_below, margin, stats)
 
 
 def ms_iterate(X, bw, iters):

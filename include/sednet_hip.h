@@ -113,6 +113,11 @@ int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, c
 int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                               float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
                               const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
+/* Farthest-point pivot rows for the row order of the block-sparse schedules: greedy k-centre on the unit sphere among rows
+ * 0, stride, 2 stride, ... (<= 4096 candidates per cloud), all P steps in one launch. picks [B,P] row indices (the first is
+ * row 0), picked [B,P,128] those rows. d = 128. */
+int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, int* picks, float* picked,
+                       sed_stream_t stream);
 /* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel). X: unit rows
  * sorted so that 32-row tiles are cluster-pure (any order is correct; the order decides how much is skipped). Every tile t
  * has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
@@ -120,8 +125,9 @@ int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, c
  * unused rows zero; tile_cosalpha [B, nref]: the smallest dot product of a row of the group with its reference. Every
  * iteration every wave measures its 32 queries against all references on the matrix pipe and skips the blocks with
  * angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for all its queries and both references. workspace: stage
- * images of rows and references; stats: NULL or 4 device uint64 counters that are ADDED to (stage visits of workgroups,
- * first products of waves, second products of waves, stages x iterations per wave = the dense count). Clouds whose rows
+ * images of rows and references; stats: NULL or 5 device uint64 counters that are ADDED to (stage visits of workgroups,
+ * first products of waves, second products of waves, stages x iterations per wave = the dense count, mask / list
+ * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.03 rad). Clouds whose rows
  * are not unit vectors run the exact dense fp32 kernel. N <= 16 384. */
 int sed_ms_iterate_bounds_f16_refs(int N);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);

@@ -1001,8 +1001,8 @@ extern "C" int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const f
 // nref = sed_ms_iterate_bounds_f16_refs(N) (unused rows zero); tile_cosalpha [B, nref]: the smallest dot product between a
 // row of the group and its reference. A 32 x 32 block is skipped when every query of the wave satisfies
 // angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for both references (=> all its weights <= e^skip_below). workspace = sed_ms_iterate_bounds_f16_workspace_bytes(B, N);
-// stats: NULL or 4 device uint64 counters that are ADDED to (workgroup stage visits, wave first products, wave second
-// products, stages x iterations per wave = the dense count). Clouds whose rows are not unit vectors run the exact dense
+// stats: NULL or 5 device uint64 counters that are ADDED to (workgroup stage visits, wave first products, wave second
+// products, stages x iterations per wave = the dense count, mask / list constructions of workgroups). Clouds whose rows are not unit vectors run the exact dense
 // fp32 kernel instead (same flag as the dense split-fp16 schedule). N <= 16 384, d = 128.
 extern "C" int sed_ms_iterate_bounds_f16_refs(int N) { return N > 0 ? 2 * ((((N + 31) / 32) + 31) / 32) * 32 : 0; }
 

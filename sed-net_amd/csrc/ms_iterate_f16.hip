@@ -586,6 +586,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
 
 constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
+constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
 constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
 
 template <bool STAGGER>
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     __shared__ unsigned long long wmask[8][MAXW];
     __shared__ int slist[512];
     __shared__ int wcount[8];
+    __shared__ float wmoved[8];
     __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
     {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
         const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
-        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin : 1.0e9f;
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
         for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
             float v = 3.0e38f;                           // references of tiles past the end: never near
             const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
@@ -698,9 +700,37 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float rsum = 0.f;
     h16x8 ph[2], pl[2];
-    unsigned long long n_listed = 0, n_first = 0, n_second = 0;      // per-wave counts (statistics only)
+    unsigned long long n_listed = 0, n_first = 0, n_second = 0, n_remake = 0;      // per-wave counts (statistics only)
 
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
+    // The rows at mask time are parked in the output rows (row-private; overwritten by the result at the end).
+    int ns = 0;
     for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous iteration's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) mx = fmaxf(mx, wmoved[w]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+        if (qrow < N) {                                  // remember where the masks were made: the row's slot of the output
+            float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 4 * g + u;
+                        v[u] = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                    }
+                    *(f32x4*)(keep + 32 * c + 8 * g + 4 * hi) = v;
+                }
+        }
         // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
         for (int g0 = 0; g0 < nrs; g0 += F16S_REFGROUP) {
             const int ng = min(F16S_REFGROUP, nrs - g0);
@@ -740,7 +770,6 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
         __syncthreads();
         // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
-        int ns;
         {
             bool need = false;
             if (tid < nst) {
@@ -765,6 +794,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         }
         __syncthreads();
         ns = __builtin_amdgcn_readfirstlane(ns);
+        ++n_remake;
+        }   // remake
         n_listed += ns;
 
         // ---- (4) the pipeline over the list
@@ -864,6 +895,29 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
+        if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
+            float ch2 = 0.f;
+            if (qrow < N) {
+                const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 k = *(const f32x4*)(keep + 32 * c + 8 * g + 4 * hi);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dlt = o[c][4 * g + u] * inv - k[u];
+                            ch2 = fmaf(dlt, dlt, ch2);
+                        }
+                    }
+            }
+            ch2 += xor32(ch2);
+            float wm = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            if (lane == 0) wmoved[wave] = wm;            // read after the barrier that opens the next iteration
+        }
         if (it == iters - 1) {
             if (qrow < N) {
                 float* out = newX + ((size_t)cloud * N + qrow) * 128;
@@ -900,11 +954,12 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     }
     if (stats && lane == 0) {
         // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
-        // [3] dense count: waves x stages x iterations
+        // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
         if (wave == 0) atomicAdd(stats + 0, n_listed);
         atomicAdd(stats + 1, n_first);
         atomicAdd(stats + 2, n_second);
         atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
+        if (wave == 0) atomicAdd(stats + 4, n_remake);
     }
 }
 
@@ -1044,7 +1099,7 @@ size_t ms_f16_sparse_workspace_bytes(int B, int N) {
 // Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
 // row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
-// workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 4 x u64, accumulated).
+// workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated).
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, hipStream_t stream) {

@@ -207,16 +207,24 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     P = min(n_pivots, N)
     # farthest-point pivots (greedy k-centre on the sphere): every cluster gets at least one pivot as long as there are
     # no more clusters than pivots, so no row is left far from its pivot (a far row would need every block)
-    bidx = torch.arange(B, device=X.device)
-    dots = torch.empty((B, N, P), dtype=torch.float32, device=X.device)
-    pick = torch.zeros((B,), dtype=torch.long, device=X.device)
-    picks = []
-    closest = None
-    for j in range(P):
-        picks.append(pick)
-        dots[:, :, j] = torch.bmm(X, X[bidx, pick].unsqueeze(2)).squeeze(2)
-        closest = dots[:, :, j] if closest is None else torch.maximum(closest, dots[:, :, j])
-        pick = closest.argmin(1)
+    # (picked among every `stride`-th row: the greedy loop is 64 dependent passes over the rows it looks at, and a quarter of
+    # a 10 000-point cloud still holds a dozen rows of a cluster of 0.5 % of the points)
+    stride = 4 if N >= 4096 else 1
+    picked = torch.empty((B, P, D), dtype=torch.float32, device=X.device)
+    if D == 128 and X.is_cuda and (N + stride - 1) // stride <= 4096:
+        picks = torch.empty((B, P), dtype=torch.int32, device=X.device)
+        check(lib.sed_fps_pivots_f32(B, N, D, stride, P, ptr(X), ptr(picks), ptr(picked), stream()), "fps_pivots")
+    else:
+        Xf = X[:, ::stride].contiguous() if stride > 1 else X
+        bidx = torch.arange(B, device=X.device)
+        pick = torch.zeros((B,), dtype=torch.long, device=X.device)
+        closest = None
+        for j in range(P):
+            picked[:, j] = Xf[bidx, pick]
+            dj = torch.bmm(Xf, picked[:, j].unsqueeze(2)).squeeze(2)
+            closest = dj if closest is None else torch.maximum(closest, dj)
+            pick = closest.argmin(1)
+    dots = torch.bmm(X, picked.transpose(1, 2))
     # one k-means step: reference directions = normalised means of the pivot groups (any unit vectors are valid
     # references; the mean sits in the middle of its group, which tightens every angular bound by about a third)
     grp = dots.argmax(2)
@@ -319,7 +327,7 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, 
     caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
     bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
     f16 (with bounds): products on the fp16 matrix pipe and bounds from the exact angle of every query to every tile's
-    mean (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional int64 [4] device tensor the kernel adds its visit
+    mean (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional int64 [5] device tensor the kernel adds its visit
     counts to."""
     return ms_sparse_run(ms_sparse_prepare(X, n_pivots, bounds, f16), bw, iters, skip_below, margin, stats)
 

@@ -208,10 +208,11 @@ def test_block_sparse_schedule(T):
         sparse = ops.ms_iterate_sparse(X, bw, 50, -30.0, bounds=bounds, f16=f16)
         np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), atol=2e-5 if not f16 else 3e-6)
     # the split-fp16 sparse kernel counts what it visits: a small share of the dense schedule on clustered rows
-    stats = T.zeros(4, dtype=T.int64, device="cuda")
+    stats = T.zeros(5, dtype=T.int64, device="cuda")
     ops.ms_iterate_sparse(X, bw, 50, -30.0, stats=stats)
     st = stats.cpu().numpy().astype(np.float64)
     assert st[3] == 3 * 39 * 8 * 312 * 50 and st[1] / st[3] < 0.25 and st[2] <= st[1]
+    assert 3 * 39 <= st[4] <= 3 * 39 * 10                   # masks and lists are rebuilt only while the rows still move
     order = ops.ms_pivot_order(X)[0]
     assert (T.sort(order, 1)[0] == T.arange(9973, device="cuda")[None]).all()          # a permutation per cloud
     # "auto" (the default) picks the sparse schedule for these clouds and the dense one for unstructured rows, per cloud
@@ -290,6 +291,39 @@ def test_fused_kth_distance_is_bit_identical(T, N, d, K, B):
                 assert T.equal(kth_f, kth_m)
             else:
                 assert K2 > 160
+
+
+def test_farthest_point_pivots_kernel(T):
+    """sed_fps_pivots_f32 (all greedy steps in one launch) against the step-by-step host loop on the same candidates: the
+    same picks wherever the arg-min is not a near-tie, the same k-centre radius at every step count checked."""
+    from sednet_hip import synth
+    from sednet_hip._lib import check, lib, ptr, stream
+    Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + 4 * c, sigma=0.01, seed=40 + c)[0] for c in range(3)])
+    X = dev(T, Xs)
+    B, N, D = X.shape
+    P, stride = 64, 4
+    picks = T.empty((B, P), dtype=T.int32, device="cuda")
+    picked = T.empty((B, P, D), dtype=T.float32, device="cuda")
+    check(lib.sed_fps_pivots_f32(B, N, D, stride, P, ptr(X), ptr(picks), ptr(picked), stream()), "fps")
+    pk = picks.cpu().numpy()
+    assert (pk[:, 0] == 0).all() and (pk % stride == 0).all()
+    assert all(len(set(pk[b])) == P for b in range(B))
+    assert T.equal(picked, X[T.arange(B, device="cuda")[:, None], picks.long()])
+    Xf = X[:, ::stride]
+    closest = T.full((B, Xf.shape[1]), -2.0, device="cuda")
+    ck = T.full((B, Xf.shape[1]), -2.0, device="cuda")
+    pick = T.zeros(B, dtype=T.long, device="cuda")
+    bidx = T.arange(B, device="cuda")
+    same = 0
+    for j in range(P):
+        closest = T.maximum(closest, (Xf * Xf[bidx, pick][:, None]).sum(2))
+        ck = T.maximum(ck, (Xf * picked[:, j][:, None]).sum(2))
+        same += int((pick.cpu().numpy() * stride == pk[:, j]).sum())
+        np.testing.assert_allclose(ck.min(1)[0].cpu().numpy(), closest.min(1)[0].cpu().numpy(), atol=2e-3)   # k-centre radius
+        pick = closest.argmin(1)
+    assert same >= 0.8 * B * P
+    assert lib.sed_fps_pivots_f32(B, N, 64, stride, P, ptr(X), ptr(picks), ptr(picked), stream()) == -2
+    assert lib.sed_fps_pivots_f32(B, 20000, D, 4, P, ptr(X), ptr(picks), ptr(picked), stream()) == -2
 
 
 def test_fused_kth_overflow_is_per_cloud(T):

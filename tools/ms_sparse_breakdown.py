@@ -24,3 +24,14 @@ _, t_kern = t(lambda: ops.ms_sparse_run(prep, bw, 50))
 _, t_order = t(lambda: ops.ms_pivot_order(X))
 _, t_probe = t(lambda: ops.ms_near_fraction(X, bw).cpu())
 print(f"B={B}: whole call {t_all:.2f} ms = prepare {t_prep:.2f} (pivot order {t_order:.2f}) + kernels+unsort {t_kern:.2f}; probe {t_probe:.2f}")
+# fixed per-iteration cost of the sparse kernel: unstructured rows (every stage listed) against the dense kernel
+Xr = torch.nn.functional.normalize(torch.randn(B, 10000, 128, device="cuda"), dim=2)
+bwr = ops.ms_bandwidth(Xr, 150, 0.003)
+prep_r = ops.ms_sparse_prepare(Xr)
+ops.ms_set_variant("f16")
+for it in (10, 20):
+    _, td = t(lambda: ops._ms_iterate_dense(Xr, bwr, it))
+    _, ts = t(lambda: ops.ms_sparse_run(prep_r, bwr, it))
+    print(f"unstructured rows, {it} iterations: dense kernel {td:.2f} ms, sparse kernel with full lists {ts:.2f} ms "
+          f"-> {(ts - td) / it * 1e3 / ((B * 40 + 255) // 256):.1f} us per iteration and workgroup round")
+ops.ms_set_variant("auto")

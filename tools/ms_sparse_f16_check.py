@@ -18,7 +18,7 @@ def t(f):
 
 ops.ms_set_variant("f16")
 d, td = t(lambda: ops._ms_iterate_dense(X, bw, 50))
-stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+stats = torch.zeros(5, dtype=torch.int64, device="cuda")
 s, ts = t(lambda: ops.ms_iterate_sparse(X, bw, 50, -30.0, stats=stats))
 st = (stats // 2).tolist()                  # t() runs twice
 s32, ts32 = t(lambda: ops.ms_iterate_sparse(X, bw, 50, -30.0, f16=False))
@@ -27,7 +27,7 @@ print(f"max |sparse f16 - dense f16| {(d - s).abs().max().item():.2e}   max |spa
 nwg = B * ((10000 + 255) // 256)
 dense_wg = nwg * 313 * 50
 print(f"stage visits of workgroups {st[0]} = {st[0] / dense_wg:.3f} of dense; wave first products {st[1] / st[3]:.3f}, "
-      f"second products {st[2] / st[3]:.3f} of dense")
+      f"second products {st[2] / st[3]:.3f} of dense; masks rebuilt {st[4] / nwg:.1f} times per workgroup")
 _, to = t(lambda: ops.ms_pivot_order(X))
 print(f"pivot order {to:.2f} ms")
 Xr = torch.nn.functional.normalize(torch.randn(2, 10000, 128, device="cuda"), dim=2)

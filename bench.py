@@ -219,6 +219,9 @@ def main():
 
     # dominant kernel: mean of the ms_iterate launch durations inside the timed region
     it = [(s.elapsed_time(e), meta) for (name, s, e, meta) in timers if name == "ms_iterate"]
+    if not it:       # every cloud took the block-sparse schedule: report that kernel against the same algorithmic flops
+        it = [(s.elapsed_time(e), dict(meta, schedule="split-fp16")) for (name, s, e, meta) in timers
+              if name == "ms_iterate_sparse"]
     flops_per_cloud = 4.0 * N * N * 128 * args.iterations
     avg_ms = float(np.mean([t for t, _ in it]))
     avg_clouds = float(np.mean([m["B"] for _, m in it]))
@@ -243,7 +246,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32 (mean-shift products: split-fp16 MFMA emulation, 3 fp16 MFMAs per fp32 product on exact (h,l) "
-                     "splits, fp32 accumulate, fp32-equivalent error; all other kernels fp32-input MFMA)" if split else "f32",
+                     "splits, fp32 accumulate, fp32-equivalent error; selection dot products: the same split; head GEMMs: 3-way bf16 "
+                     "splits, 6 bf16 MFMAs per product; EdgeConv: fp32-input MFMA)" if split else "f32",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: " if (B, N, args.k) == (64, 10000, 20) and not strong else
                                     (f"BASELINE configs[3]-style fixed job of {args.total_clouds} clouds: " if strong else "")) +
@@ -279,9 +283,12 @@ def main():
         guard = (min(17, hi - lo - 1),) if world == 1 else ((min(3, hi - lo - 1), min(17, hi - lo - 1)) if rank == 0 else ())
         X_r, planted = synth.planted_embedding(l_np, d=128, sigma=0.01, seed=3 + rank, guard_clouds=guard)
         t_r = torch.from_numpy(t_np.astype(np.int32)).to(dev)
-        out_r, el_r, _, st_r = timed(lambda: step(X_r, t_r))
+        ops.MS_SPARSE_STATS.update(sparse_clouds=0, dense_clouds=0)
+        out_r, el_r, tm_r, st_r = timed(lambda: step(X_r, t_r))
         if rank == 0:
             nl = np.asarray(out_r["n_labels"])
+            sp = [(s.elapsed_time(e), m) for (name, s, e, m) in tm_r if name == "ms_iterate_sparse"]
+            runs = args.steps + args.warmup
             line["realistic"] = {
                 "value": round((args.total_clouds if strong else B * world) * args.steps / el_r, 3), "unit": "clouds/s",
                 "ms_per_step": round(el_r / args.steps * 1e3, 2),
@@ -290,6 +297,15 @@ def main():
                 "mean_shift_passes_per_cloud": round(float(np.mean(out_r["passes"])), 4),
                 "clouds_with_guard_retries": int((np.asarray(out_r["passes"]) > 1).sum()),
                 "stages_ms_per_step": {k_: round(v, 2) for k_, v in st_r.items()},
+                "mean_shift_schedule": {
+                    "sparse_cloud_passes_per_step": ops.MS_SPARSE_STATS["sparse_clouds"] / runs,
+                    "dense_cloud_passes_per_step": ops.MS_SPARSE_STATS["dense_clouds"] / runs,
+                    "sparse_kernel_ms": round(float(np.mean([t for t, _ in sp])), 2) if sp else None,
+                    "dense_equivalent_tflops": round(float(np.mean([flops_per_cloud * m["B"] / (t * 1e-3) / 1e12
+                                                                    for t, m in sp])), 1) if sp else None,
+                    "note": "clouds whose embedding the density probe finds clustered run ms_iterate_d128_f16s_kernel "
+                            "(block-sparse split-fp16: blocks with all weights <= e^-30 skipped); dense_equivalent_tflops "
+                            "= the dense schedule's algorithmic flops / the sparse launch time (incl. the stage-image kernels)"},
                 "note": "same step; embedding and per-point types replaced after both forwards by ones carrying each cloud's "
                         "true segments (sednet_hip.synth.planted_embedding), one cloud built to exceed 49 clusters"}
     if rank == 0:

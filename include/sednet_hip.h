@@ -53,7 +53,7 @@ int sed_row_topk_idx_f32(int B, int N, int ldD, int k, const float* D, int* idx,
 
 /* Fused streaming kNN (two score sweeps + short candidate lists, no N x N matrix). *overflow (device int) is set to
  * 1 when a candidate list overflowed (masses of duplicate points): the result is then invalid and the caller falls
- * back to sed_pairdist_* + sed_row_topk_idx_f32. k <= sed_knn_fused_max_k() (85); the xyz-normal variant k <= 42.
+ * back to sed_pairdist_* + sed_row_topk_idx_f32. k <= sed_knn_fused_max_k() (85), both variants.
  * src/PointNet.py:62-87 (knn) and :90-137 (knn_points_normals) */
 size_t sed_knn_fused_workspace_bytes(int B, int N);
 int sed_knn_fused_max_k(void);

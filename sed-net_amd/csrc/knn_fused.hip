@@ -434,18 +434,29 @@ static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int
 extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws,
                                     size_t ws_bytes, int* overflow, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || k > N || !x6 || !idx || !ws || !overflow) return SED_EINVAL;
-    if (k > 42) return SED_EUNSUPPORTED;                       // M <= 2 keeps the per-thread bucket arrays in registers
+    if (k > 85) return SED_EUNSUPPORTED;                       // M <= 4: 128 bucket registers per thread
     if (ws_bytes < sed_knn_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const Ws w = carve(ws, B, N);
     hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid((N + 255) / 256, B);
-    if (pick_M(k) == 1) {
-        knn_pn_sweep_kernel<1, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-        knn_pn_sweep_kernel<1, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-    } else {
-        knn_pn_sweep_kernel<2, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-        knn_pn_sweep_kernel<2, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+    switch (pick_M(k)) {
+        case 1:
+            knn_pn_sweep_kernel<1, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<1, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            break;
+        case 2:
+            knn_pn_sweep_kernel<2, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<2, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            break;
+        case 3:                                                // k = 64, the reference script's default (round 2)
+            knn_pn_sweep_kernel<3, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<3, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            break;
+        default:
+            knn_pn_sweep_kernel<4, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<4, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            break;
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;

@@ -111,7 +111,7 @@ def knn_points_normals(x6, k, W=1.0):
     B, _, N = x6.shape
     x6 = x6.contiguous().float()
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x6.device)
-    if FUSED_KNN and k <= 42 and N >= 32:
+    if FUSED_KNN and k <= 85 and N >= 32:
         ws, nbytes = _fused_ws(B, N, x6.device)
         flag = torch.empty((1,), dtype=torch.int32, device=x6.device)
         check(lib.sed_knn_pn_fused_f32(B, N, k, float(W), ptr(x6), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()),

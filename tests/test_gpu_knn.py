@@ -98,12 +98,14 @@ def test_fused_knn_overflow_falls_back_to_exact_path(T):
         b = knn(dev(T, y), 20, 20).cpu().numpy()
         p, n, _, _ = __import__("sednet_hip.synth", fromlist=["x"]).synthetic_cloud(5, 1500)
         x6 = np.concatenate([p, n], 1).T[None]
-        c_exact = knn_points_normals(dev(T, x6), 20, 20).cpu().numpy()
+        c_exact = {k: knn_points_normals(dev(T, x6), k, k).cpu().numpy() for k in (20, 40, 64, 85)}
     finally:
         ops.FUSED_KNN = True
     np.testing.assert_array_equal(a, b)                             # same scores, same tie rule: bit-identical
-    c_fused = knn_points_normals(dev(T, x6), 20, 20).cpu().numpy()
-    np.testing.assert_array_equal(c_fused, c_exact)
+    before = dict(ops.FUSED_STATS)
+    for k in (20, 40, 64, 85):                                      # bucket depths M = 1 .. 4; 64 = the script's default k
+        np.testing.assert_array_equal(knn_points_normals(dev(T, x6), k, k).cpu().numpy(), c_exact[k])
+    assert ops.FUSED_STATS["fused"] == before["fused"] + 4
 
 
 @pytest.mark.parametrize("k", [20, 32, 33])

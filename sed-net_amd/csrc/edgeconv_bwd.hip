@@ -236,7 +236,11 @@ __global__ void edgeconv_bwd_weight_reduce_kernel(const float* __restrict__ part
 // directly the B operand of the second MFMA (K = output channels). One workgroup = 128 points x one 32-channel output
 // slab (blockIdx.z); the slabs' contributions meet in dx through fp32 atomics, like the neighbour scatter itself
 // (torch's own index_select backward is atomic too).   grid (ceil(N/128), B, Cout/32)
-template <int CH>
+// DET (default of the host wrapper, round 2): nothing is accumulated with atomics. Every (slab, edge) contribution is
+// stored to E [cloud][slab][p k + j][C] and every (slab, point) self term to dxself [cloud][slab][p][C]; edge_gather_kernel
+// then sums, per target row, the self terms and the contributions of its incoming edges in ascending edge order (reverse
+// graph = the edge ids stably sorted by target) -- the same bits on every run.
+template <int CH, bool DET>
 __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float* __restrict__ x, int ldx,
                                                                     const int* __restrict__ idx, int k,
                                                                     const float* __restrict__ W1t,
@@ -244,7 +248,8 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
                                                                     const float* __restrict__ S,
                                                                     const uint8_t* __restrict__ jsel,
                                                                     const float* __restrict__ ak,
-                                                                    float* __restrict__ dx, int lddx, int N) {
+                                                                    float* __restrict__ dx, int lddx, int N,
+                                                                    float* __restrict__ E, float* __restrict__ dxself) {
     constexpr int C = 2 * CH, LDW = 33, TC = C / 32, LDT = C + 1;
     __shared__ float w1[C * LDW], w2[C * LDW];
     __shared__ float tr[4][32 * LDT];        // per-wave transpose tile: df[point][channel] -> channel-major rows
@@ -321,9 +326,16 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int q = 0; q < 32; ++q) {
-            const int row = __shfl(ok ? nb : -1, q, 64);
-            if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
+        if (DET) {
+            float* Eb = E + ((size_t)cloud * gridDim.z + blockIdx.z) * N * k * C;
+            const int pq0 = blockIdx.x * 128 + wave * 32;
+            for (int q = 0; q < 32; ++q)
+                if (pq0 + q < N && lane < C) Eb[((size_t)(pq0 + q) * k + j) * C + lane] = mytr[q * LDT + lane];
+        } else {
+            for (int q = 0; q < 32; ++q) {
+                const int row = __shfl(ok ? nb : -1, q, 64);
+                if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -340,11 +352,56 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
             for (int r = 0; r < 16; ++r) mytr[li * LDT + 32 * tc + mfma_row(r, hi)] = dxc[tc][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int q = 0; q < 32; ++q) {
-            const int row = __shfl(ok ? p : -1, q, 64);
-            if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
+        if (DET) {
+            float* sb = dxself + ((size_t)cloud * gridDim.z + blockIdx.z) * N * C;
+            const int pq0 = blockIdx.x * 128 + wave * 32;
+            for (int q = 0; q < 32; ++q)
+                if (pq0 + q < N && lane < C) sb[(size_t)(pq0 + q) * C + lane] = mytr[q * LDT + lane];
+        } else {
+            for (int q = 0; q < 32; ++q) {
+                const int row = __shfl(ok ? p : -1, q, 64);
+                if (row >= 0 && lane < C) atomicAdd(dxb + (size_t)row * lddx + lane, mytr[q * LDT + lane]);
+            }
         }
     }
+}
+
+// dx[t] = sum_slab dxself[slab][t] + sum over the incoming edges e of t (ascending) of sum_slab E[slab][e].
+// One wave per target row, lane = channel (C = 64).   grid (ceil(N / 4), B)
+__global__ __launch_bounds__(256) void edge_gather_kernel(const float* __restrict__ E, const float* __restrict__ dxself,
+                                                          const int* __restrict__ rptr, const int* __restrict__ redge,
+                                                          int nslab, int N, int k, float* __restrict__ dx, int lddx) {
+    constexpr int C = 64;
+    const int cloud = blockIdx.y, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= N) return;
+    const size_t ne = (size_t)N * k;
+    const float* Ec = E + (size_t)cloud * nslab * ne * C;
+    const float* sc = dxself + (size_t)cloud * nslab * N * C;
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) acc += sc[((size_t)s * N + t) * C + lane];
+    const int* rp = rptr + (size_t)cloud * (N + 1);
+    const int* re = redge + (size_t)cloud * ne;
+    const int i1 = rp[t + 1];
+    int i = rp[t];
+    for (; i + 4 <= i1; i += 4) {                          // four edges in flight; summed in order
+        const int e0 = re[i], e1 = re[i + 1], e2 = re[i + 2], e3 = re[i + 3];
+        float v[4][4];
+        for (int s = 0; s < nslab && s < 4; ++s) {
+            v[0][s] = Ec[((size_t)s * ne + e0) * C + lane];
+            v[1][s] = Ec[((size_t)s * ne + e1) * C + lane];
+            v[2][s] = Ec[((size_t)s * ne + e2) * C + lane];
+            v[3][s] = Ec[((size_t)s * ne + e3) * C + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (int s = 0; s < nslab && s < 4; ++s) acc += v[u][s];
+    }
+    for (; i < i1; ++i) {
+        const int e = re[i];
+        for (int s = 0; s < nslab; ++s) acc += Ec[((size_t)s * ne + e) * C + lane];
+    }
+    dx[((size_t)cloud * N + t) * lddx + lane] = acc;
 }
 
 }  // namespace
@@ -397,13 +454,23 @@ extern "C" size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout)
     return (size_t)B * edgeconv_bwd_nwg(N) * 4 * 2 * C * Cout * sizeof(float);
 }
 
+extern "C" size_t sed_edgeconv_bwd_edge_ws_bytes(int B, int N, int C, int Cout, int k) {
+    return (size_t)B * (Cout / 32) * ((size_t)N * k + N) * C * sizeof(float);
+}
+
 // EdgeConv backward. Inputs as the forward plus S [B,N,Cout], jsel [B,N,Cout], ak [B,G,2] (sed_gn_bwd_reduce_f32 on
 // dout / ysel with count = Cout/G * N * k). Outputs dW1t, dW2t [C][Cout] (overwritten) and, when dx != NULL,
-// dx [B,N,lddx] accumulated with atomics (caller zero-initialises; only C = 64 layers have an input gradient).
+// dx [B,N,lddx] (only C = 64 layers have an input gradient):
+//   * rptr == NULL: accumulated with fp32 atomics (caller zero-initialises; order of the additions varies run to run);
+//   * rptr [B,N+1], redge [B,N k] = the reverse graph (edge ids p k + j stably sorted by their target idx[p][j], row t =
+//     redge[rptr[t] .. rptr[t+1])) and edge_ws (sed_edgeconv_bwd_edge_ws_bytes): deterministic -- per-edge contributions
+//     are stored and gathered per target row in ascending edge order; columns 0..63 of dx are overwritten, the rest is left
+//     alone. Up to 4 slabs (Cout <= 128).
 extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
                                     const int* idx, const float* W1t, const float* W2t, const float* S,
                                     const uint8_t* jsel, const float* ak, float* dW1t, float* dW2t, float* dx,
-                                    int lddx, void* partials, size_t partials_bytes, hipStream_t stream) {
+                                    int lddx, void* partials, size_t partials_bytes, const int* rptr, const int* redge,
+                                    void* edge_ws, size_t edge_ws_bytes, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || k > 255 || !x || !idx || !W1t || !W2t || !S || !jsel || !ak || !dW1t || !dW2t ||
         !partials)
         return SED_EINVAL;
@@ -428,8 +495,20 @@ extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G,
     SED_LAUNCH_CHECK();
     if (dx) {
         if (C != 64 || lddx < C) return SED_EUNSUPPORTED;
-        edgeconv_bwd_input_kernel<32><<<dim3((N + 127) / 128, B, Cout / 32), 256, 0, stream>>>(
-            x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, dx, lddx, N);
+        const dim3 ig((N + 127) / 128, B, Cout / 32);
+        if (rptr) {
+            if (!redge || !edge_ws || Cout > 128) return SED_EINVAL;
+            if (edge_ws_bytes < sed_edgeconv_bwd_edge_ws_bytes(B, N, C, Cout, k)) return SED_EINVAL;
+            float* E = (float*)edge_ws;
+            float* dxself = E + (size_t)B * (Cout / 32) * N * k * C;
+            edgeconv_bwd_input_kernel<32, true><<<ig, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, dx,
+                                                                         lddx, N, E, dxself);
+            SED_LAUNCH_CHECK();
+            edge_gather_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(E, dxself, rptr, redge, Cout / 32, N, k, dx, lddx);
+        } else {
+            edgeconv_bwd_input_kernel<32, false><<<ig, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak,
+                                                                          dx, lddx, N, nullptr, nullptr);
+        }
         SED_LAUNCH_CHECK();
     }
     return SED_OK;

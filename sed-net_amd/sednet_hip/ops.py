@@ -464,7 +464,20 @@ def gn_bwd_apply(S, y, C, G, ak):
     return S
 
 
-def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx):
+DETERMINISTIC_BWD = True    # EdgeConv input gradients by reverse-graph gather (same bits every run); False: fp32 atomics
+
+
+def reverse_graph(idx):
+    """idx [B,N,k] int32 -> (rptr [B,N+1] int32, redge [B,N k] int32): edge ids p k + j stably sorted by target idx[p,j];
+    the incoming edges of row t are redge[rptr[t] : rptr[t+1]], ascending."""
+    B, N, k = idx.shape
+    tgt, order = torch.sort(idx.reshape(B, N * k), dim=1, stable=True)
+    bounds = torch.arange(N + 1, device=idx.device, dtype=tgt.dtype).unsqueeze(0).expand(B, N + 1).contiguous()
+    rptr = torch.searchsorted(tgt.contiguous(), bounds).int().contiguous()
+    return rptr, order.int().contiguous()
+
+
+def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=None):
     """-> (dW1t [C,Cout], dW2t [C,Cout], dx [B,N,ldx] or None)."""
     B, N, ldx = x.shape
     k = idx.shape[2]
@@ -475,9 +488,17 @@ def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx):
     dx = torch.zeros((B, N, ldx), dtype=torch.float32, device=dev) if need_dx else None
     nb = lib.sed_edgeconv_bwd_partials_bytes(B, N, C, Cout)
     part = _bytes(nb, dev)
+    det = DETERMINISTIC_BWD if deterministic is None else deterministic
+    rptr = redge = ews = None
+    nws = 0
+    if need_dx and det and Cout <= 128:
+        rptr, redge = reverse_graph(idx)
+        nws = lib.sed_edgeconv_bwd_edge_ws_bytes(B, N, C, Cout, k)
+        ews = torch.empty((nws,), dtype=torch.uint8, device=dev)
     check(lib.sed_edgeconv_bwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(S), ptr(jsel),
                                    ptr(ak), ptr(dW1t), ptr(dW2t), ptr(dx) if need_dx else None, ldx, ptr(part), nb,
-                                   stream()), "edgeconv_bwd")
+                                   ptr(rptr) if rptr is not None else None, ptr(redge) if redge is not None else None,
+                                   ptr(ews) if ews is not None else None, nws, stream()), "edgeconv_bwd")
     return dW1t, dW2t, dx
 
 

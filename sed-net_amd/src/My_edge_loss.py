@@ -19,14 +19,16 @@ def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
     pull = torch.zeros(1, device=dev)
     push = torch.zeros(1, device=dev)
     for i in range(B):
-        # segment statistics by scatter-add instead of the reference's per-segment Python loop (same terms)
+        # segment statistics by one-hot products instead of the reference's per-segment Python loop (same terms; a
+        # scatter-add / index_add_ would do too, but its fp32 atomics -- forward and in the backward of C[inv] -- make the
+        # gradients differ from run to run, and the training step is otherwise bit-reproducible)
         _, inv, cnt = torch.unique(gt_label[i], return_inverse=True, return_counts=True)
         S = cnt.shape[0]
         cntf = cnt.to(pred_feat.dtype)
-        C = torch.zeros((S, pred_feat.shape[2]), dtype=pred_feat.dtype, device=dev).index_add_(0, inv, pred_feat[i])
-        C = C / cntf[:, None]
-        excess = F.relu(torch.norm(pred_feat[i] - C[inv], 2, dim=1) - t_pull)
-        per_seg = torch.zeros(S, dtype=pred_feat.dtype, device=dev).index_add_(0, inv, excess) / cntf
+        onehot = (inv[None, :] == torch.arange(S, device=dev)[:, None]).to(pred_feat.dtype)        # [S, M]
+        C = (onehot @ pred_feat[i]) / cntf[:, None]
+        excess = F.relu(torch.norm(pred_feat[i] - onehot.t() @ C, 2, dim=1) - t_pull)
+        per_seg = (onehot @ excess) / cntf
         pull = pull + per_seg.sum() / S
         if S == 1:
             continue

@@ -32,8 +32,10 @@ class EmbeddingLoss:
             picks.append({l: np.random.choice(np.where(labels[i] == l)[0], n_s, replace=True)
                           for l in uniq})
         # all np.random draws happen on the host in the reference's order; the tensor work of one cloud is then batched
-        # over its sampled segment pairs instead of the reference's per-pair Python loop (same terms, one launch set)
-        total = torch.zeros(1, device=dev)
+        # over its sampled segment pairs instead of the reference's per-pair Python loop (same terms, one launch set).
+        # The sampled rows of ALL clouds are gathered from `out` in ONE indexing op: per-cloud `out[i, idx]` makes autograd
+        # build (and add up) a full [B,N,D] gradient per cloud -- 26 ms of a 186 ms training step at 32 x 10 000 points.
+        plan, flat, off = [], [], 0
         single = 0
         for i in range(B):
             keys = sorted(picks[i].keys())
@@ -49,8 +51,16 @@ class EmbeddingLoss:
                     pairs.append((k1, k2))
             if not pairs:
                 continue                                             # acc = 0 / (0 + 1e-8)
-            seg = out[i, torch.as_tensor(np.stack([picks[i][k] for k in keys]), device=dev)]     # [nk, ns, D]
-            pr = torch.as_tensor(np.asarray(pairs), device=dev)
+            rows = np.stack([picks[i][k] for k in keys])             # [nk, ns]
+            plan.append((off, rows.shape, np.asarray(pairs)))
+            flat.append(rows.reshape(-1).astype(np.int64) + i * N)
+            off += rows.size
+        total = torch.zeros(1, device=dev)
+        if plan:
+            G = out.reshape(B * N, -1)[torch.as_tensor(np.concatenate(flat), device=dev)]        # [sum nk ns, D]
+        for o, (nk, ns), pairs in plan:
+            seg = G[o:o + nk * ns].view(nk, ns, -1)
+            pr = torch.as_tensor(pairs, device=dev)
             a, b = seg[pr[:, 0]], seg[pr[:, 1]]                                                   # [P, ns, D]
             d_pos = ((a[:, :, None] - a[:, None]) ** 2).sum(3)
             d_neg = ((a[:, :, None] - b[:, None]) ** 2).sum(3)

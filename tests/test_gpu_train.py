@@ -60,6 +60,43 @@ def test_edgeconv_backward_matches_autograd(T, C, Cout, N, k, B):
         close(xg.grad.cpu().numpy()[:, :, :C].transpose(0, 2, 1), xc.grad.numpy(), 2e-4, "dx")
 
 
+@pytest.mark.parametrize("Cout,N,k,B", [(64, 1000, 20, 3), (128, 777, 64, 2)])
+def test_edgeconv_input_gradient_is_deterministic(T, Cout, N, k, B):
+    """Default backward (ops.DETERMINISTIC_BWD): per-edge contributions stored and gathered per target row in ascending edge
+    order through the reverse graph -- the same bits on every run, equal to the fp32-atomic path up to summation order; the
+    reverse graph lists, per target, exactly its incoming edges in ascending order (hub rows with hundreds of them)."""
+    from sednet_hip import ops
+    g = T.Generator().manual_seed(N + k)
+    C = 64
+    x = T.randn(B, N, C, generator=g).cuda()
+    # a hubby graph: half of every point's neighbours come from the first 20 rows
+    idx = T.randint(0, N, (B, N, k), generator=g)
+    idx[:, :, ::2] = T.randint(0, 20, (B, N, (k + 1) // 2), generator=g)
+    idx = idx.int().cuda()
+    rptr, redge = ops.reverse_graph(idx)
+    flat = idx.reshape(B, N * k).cpu().numpy()
+    rp, re = rptr.cpu().numpy(), redge.cpu().numpy()
+    assert (rp[:, 0] == 0).all() and (rp[:, -1] == N * k).all()
+    for b in range(B):
+        for t in (0, 7, 19, 20, N // 2, N - 1):
+            mine = re[b, rp[b, t]:rp[b, t + 1]]
+            np.testing.assert_array_equal(mine, np.nonzero(flat[b] == t)[0])          # all of them, ascending
+    assert int((rp[:, 1:21] - rp[:, 0:20]).max()) > 10 * k
+    W1t = (T.randn(C, Cout, generator=g) / 8).cuda()
+    W2t = (T.randn(C, Cout, generator=g) / 8).cuda()
+    S = T.randn(B, N, Cout, generator=g).cuda()
+    jsel = T.randint(0, k, (B, N, Cout), generator=g).to(T.uint8).cuda()
+    ak = (T.randn(B, 2, 2, generator=g) * 0.1).cuda()
+    runs = [ops.edgeconv_bwd(x, C, idx, W1t, W2t, 2, S, jsel, ak, True, deterministic=True) for _ in range(3)]
+    for r in runs[1:]:
+        for a, b_ in zip(r, runs[0]):
+            assert T.equal(a, b_)                                                     # bit-identical run to run
+    atom = ops.edgeconv_bwd(x, C, idx, W1t, W2t, 2, S, jsel, ak, True, deterministic=False)
+    assert T.equal(atom[0], runs[0][0]) and T.equal(atom[1], runs[0][1])              # weight gradients: same kernel
+    scale = float(atom[2].abs().max())
+    np.testing.assert_allclose(runs[0][2].cpu().numpy(), atom[2].cpu().numpy(), atol=2e-5 * scale)
+
+
 @pytest.mark.parametrize("K,Cout,G,act,N,B,cb", [(256, 512, 8, 1, 333, 2, True), (256, 128, 4, 0, 200, 1, False),
                                                    (512, 256, 4, 1, 130, 3, False)])
 def test_pointwise_backward_matches_autograd(T, K, Cout, G, act, N, B, cb):
@@ -178,6 +215,29 @@ def test_training_loss_matches_reference(T, golden):
     got = np.array([loss.item(), parts["embed"], parts["type"], parts["edge"], parts["edge_embed"]])
     np.testing.assert_allclose(got, g["loss"], rtol=2e-3)
     _check_digest(g, "loss/", [(n, p.grad.cpu()) for n, p in m.named_parameters() if p.grad is not None], 2e-2)
+
+
+def test_training_gradients_are_bit_reproducible(T):
+    """The whole step -- fused forwards, HIP backward with the reverse-graph gather, own split-K GEMM, fixed-order
+    reductions, the losses' sort-based index backward -- twice from the same state: identical loss and gradients, bit for bit
+    (with the fp32-atomic scatter, ops.DETERMINISTIC_BWD = False, runs differ in the last bits)."""
+    from sednet_hip import synth
+    from sednet_hip.train import training_loss
+    from train_case import train_case
+    x, labels, types, edges, edges_w, _ = train_case(synth, 3000, 2, seed0=321)
+    batch = tuple(T.from_numpy(a).cuda() for a in (x, labels, types, edges, edges_w))
+    runs = []
+    for _ in range(3):
+        m = _model(T, 20, 3)
+        np.random.seed(7)
+        loss, _ = training_loss(m, *batch, smoothing=0.025)
+        loss.backward()
+        runs.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert len(runs[0][1]) > 40
+    for l, gr in runs[1:]:
+        assert l == runs[0][0]
+        for n, v in gr.items():
+            assert T.equal(v, runs[0][1][n]), n
 
 
 def test_training_steps_reduce_the_loss(T):

@@ -1,6 +1,8 @@
 """Fused two-sweep K-th distance against the materialised path at small batch sizes: python tools/kth_small_batch.py"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, "sed-net_amd"); sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sed-net_amd")); sys.path.insert(0, ROOT)
 from sednet_hip import ops, synth
 def t(f, reps=5):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()

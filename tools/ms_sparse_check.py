@@ -1,5 +1,7 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, "sed-net_amd"); sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sed-net_amd")); sys.path.insert(0, ROOT)
 from sednet_hip import ops, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 X = np.stack([synth.clustered_embedding(N=10000, d=128, n_clusters=12 + b % 8, sigma=0.01, seed=b)[0] for b in range(B)])

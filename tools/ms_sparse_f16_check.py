@@ -1,7 +1,9 @@
 """Block-sparse split-fp16 mean-shift (ms_iterate_d128_f16s_kernel) against the dense split-fp16 kernel on clustered
 embeddings:   python tools/ms_sparse_f16_check.py [B] [sigma]"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, "sed-net_amd"); sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sed-net_amd")); sys.path.insert(0, ROOT)
 from sednet_hip import ops, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01

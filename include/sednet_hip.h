@@ -191,13 +191,15 @@ int sed_gn_bwd_apply_f32(int B, int N, int C, int G, float* S, const float* y, i
  *   rptr == NULL: dx += with fp32 atomics (caller zero-initialises; the order of the additions varies run to run);
  *   rptr [B,N+1], redge [B,N k]: the reverse graph -- edge ids p k + j stably sorted by their target idx[p][j]; row t owns
  *   redge[rptr[t] .. rptr[t+1]) -- and edge_ws (sed_edgeconv_bwd_edge_ws_bytes): DETERMINISTIC, per-edge contributions are
- *   stored and summed per target row in ascending edge order; columns 0..63 of dx are overwritten. Cout <= 128. */
+ *   stored and summed per target row in ascending edge order; columns 0..63 of dx are overwritten. Cout <= 128.
+ *   bf16 != 0 (with the reverse graph only): input-gradient products on the bf16 matrix pipe (training, configs[4]). */
 size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout);
 size_t sed_edgeconv_bwd_edge_ws_bytes(int B, int N, int C, int Cout, int k);
 int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                          const float* W1t, const float* W2t, const float* S, const uint8_t* jsel, const float* ak,
                          float* dW1t, float* dW2t, float* dx, int lddx, void* partials, size_t partials_bytes,
-                         const int* rptr, const int* redge, void* edge_ws, size_t edge_ws_bytes, sed_stream_t stream);
+                         const int* rptr, const int* redge, void* edge_ws, size_t edge_ws_bytes, int bf16,
+                         sed_stream_t stream);
 
 /* Point-wise conv as GEMM: Y = X Wt + bias + cbias[b]; flags 1 ReLU | 2 store Y | 4 GroupNorm partial sums |
  * 8 per-channel max/min over points. Wt [K][Coutp] zero padded (K % 32 == 0, Coutp % 64 == 0).

@@ -366,6 +366,167 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
     }
 }
 
+// ---- EdgeConv input gradients on the bf16 matrix pipe (TRAIN_BF16, deterministic path only; round 2) --------------
+// One workgroup = 128 points (4 waves x 32, lane = point) x ALL output slabs: the neighbour row of an edge is gathered once
+// (prefetched one neighbour ahead), the difference formed in fp32 and rounded to bf16 like the forward does, and per slab
+//   y^T  = W1 (x_j - x_p) + W2 x_p            8 MFMAs (K = 64 input channels)
+//   dy^T = alpha + kappa y^T + S [j == j*]     fp32, then rounded
+//   df  += W1^T dy,   dxc += W2^T dy           4 + 4 MFMAs (K = 32 output channels)
+// with v_mfma_f32_32x32x16_bf16 (fp32 accumulate) -- 16 MFMAs of 32 cycles per (edge block, slab) where the fp32 kernel
+// issues 64 of 64 cycles. dy^T leaves the first product in the accumulator layout (row (r & 3) + 8 (r >> 2) + 4 hi of
+// register r); the second products take their K index in exactly that order (slot 16 u + 8 hi + i <-> row of register
+// 8 u + i), so dy is packed into its B operand without leaving the registers; W1 / W2 are staged in LDS once in both
+// layouts ([o][c] for the first product, [c][slot(o)] per slab for the second). S sits in LDS per wave (every (j, slab)
+// re-reads the point's 16 values), jsel comes from global memory. The edge contribution df (summed over slabs here, so E
+// has ONE slab: a quarter of the fp32 kernel's traffic at Cout = 128) and the self term are stored straight from the
+// accumulator layout, 16 bytes per lane and store, into the rows the gather kernel reads.  grid (ceil(N/128), B)
+typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf(bbf16x8 a, bbf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_bf16_kernel(
+    const float* __restrict__ x, int ldx, const int* __restrict__ idx, int k, const float* __restrict__ W1t,
+    const float* __restrict__ W2t, int Cout, int G, const float* __restrict__ S, const uint8_t* __restrict__ jsel,
+    const float* __restrict__ ak, int N, float* __restrict__ E, float* __restrict__ dxself) {
+    constexpr int C = 64, LDY = 72 /* bf16 per [o][c] row: 144 B */, LDD = 40 /* bf16 per [c][slot] row: 80 B */;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int nslab = Cout / 32, LDS_S = Cout + 4;
+    __bf16* W1y = (__bf16*)smem;                          // [Cout][LDY]
+    __bf16* W2y = W1y + Cout * LDY;
+    __bf16* W1d = W2y + Cout * LDY;                       // [nslab][64][LDD]
+    __bf16* W2d = W1d + nslab * C * LDD;
+    float* Ss = (float*)(W2d + nslab * C * LDD);          // [4 waves][32][LDS_S]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y;
+    for (int i = tid; i < C * Cout; i += 256) {
+        const int c = i / Cout, o = i - c * Cout;         // W*t are [c][o]
+        const float a = W1t[i], b = W2t[i];
+        W1y[o * LDY + c] = (__bf16)a;
+        W2y[o * LDY + c] = (__bf16)b;
+        const int ol = o & 31, g = ol >> 3, h2 = (ol >> 2) & 1, u3 = ol & 3;       // ol = u3 + 4 h2 + 8 g = row(r, h2), r = 4 g + u3
+        const int r = 4 * g + u3, slot = (r >> 3) * 16 + h2 * 8 + (r & 7);
+        W1d[((o >> 5) * C + c) * LDD + slot] = (__bf16)a;
+        W2d[((o >> 5) * C + c) * LDD + slot] = (__bf16)b;
+    }
+    const float* xb = x + (size_t)cloud * N * ldx;
+    const int p = blockIdx.x * 128 + wave * 32 + li;
+    const bool ok = p < N;
+    const int pc = ok ? p : N - 1;
+    float* Sw = Ss + wave * 32 * LDS_S;
+    for (int i = lane; i < 32 * (Cout / 4); i += 64) {    // this wave's 32 rows of S
+        const int row = i / (Cout / 4), c4 = i - row * (Cout / 4);
+        const int pr = blockIdx.x * 128 + wave * 32 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pr < N) v = *(const f32x4*)(S + ((size_t)cloud * N + pr) * Cout + 4 * c4);
+        *(f32x4*)(Sw + row * LDS_S + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int* ib = idx + ((size_t)cloud * N + pc) * k;
+    const uint8_t* jb = jsel + ((size_t)cloud * N + pc) * Cout;
+
+    // this lane's K slots of the first product: channels 16 t + 8 hi + i
+    float xp[4][8];
+    bbf16x8 xpB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 a = *(const f32x4*)(xb + (size_t)pc * ldx + 16 * t + 8 * hi);
+        const f32x4 b = *(const f32x4*)(xb + (size_t)pc * ldx + 16 * t + 8 * hi + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xp[t][i] = a[i]; xp[t][4 + i] = b[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xpB[t][i] = (__bf16)xp[t][i];
+    }
+    f32x16 dxc[2];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxc[tc][r] = 0.f;
+
+    f32x4 nx[8];
+    auto gather = [&](int j) {
+        const int nb = ib[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            nx[2 * t] = *(const f32x4*)(xb + (size_t)nb * ldx + 16 * t + 8 * hi);
+            nx[2 * t + 1] = *(const f32x4*)(xb + (size_t)nb * ldx + 16 * t + 8 * hi + 4);
+        }
+    };
+    gather(0);
+    float* Eb = E + ((size_t)cloud * N + pc) * k * C;     // this point's edge rows
+    for (int j = 0; j < k; ++j) {
+        bbf16x8 dB[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dB[t][i] = (__bf16)((i < 4 ? nx[2 * t][i] : nx[2 * t + 1][i - 4]) - xp[t][i]);
+        if (j + 1 < k) gather(j + 1);
+        f32x16 df[2];
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) df[tc][r] = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) {
+            f32x16 yT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yT[r] = 0.f;
+            const __bf16* w1 = W1y + (32 * sl + li) * LDY + 8 * hi;
+            const __bf16* w2 = W2y + (32 * sl + li) * LDY + 8 * hi;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                yT = mfma_bf(*(const bbf16x8*)(w2 + 16 * t), xpB[t], yT);
+                yT = mfma_bf(*(const bbf16x8*)(w1 + 16 * t), dB[t], yT);
+            }
+            const int g = (32 * sl) / (Cout / G);
+            const float alpha = ak[((size_t)cloud * G + g) * 2], kappa = ak[((size_t)cloud * G + g) * 2 + 1];
+            bbf16x8 dyB[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                   // registers 4 q .. 4 q + 3 = channels 32 sl + 8 q + 4 hi + 0..3
+                const f32x4 s4 = *(const f32x4*)(Sw + li * LDS_S + 32 * sl + 8 * q + 4 * hi);
+                const unsigned js4 = *(const unsigned*)(jb + 32 * sl + 8 * q + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * q + u;
+                    float dy = ok ? fmaf(kappa, yT[r], alpha) : 0.f;
+                    dy += (ok && (int)((js4 >> (8 * u)) & 0xffu) == j) ? s4[u] : 0.f;
+                    dyB[r >> 3][r & 7] = (__bf16)dy;
+                }
+            }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const __bf16* a1 = W1d + ((sl * C) + 32 * tc + li) * LDD + 8 * hi;
+                const __bf16* a2 = W2d + ((sl * C) + 32 * tc + li) * LDD + 8 * hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    df[tc] = mfma_bf(*(const bbf16x8*)(a1 + 16 * u), dyB[u], df[tc]);
+                    dxc[tc] = mfma_bf(*(const bbf16x8*)(a2 + 16 * u), dyB[u], dxc[tc]);
+                }
+            }
+        }
+        // dx[nbr] += df (through E), dx[p] -= df
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {df[tc][4 * q], df[tc][4 * q + 1], df[tc][4 * q + 2], df[tc][4 * q + 3]};
+                if (ok) *(f32x4*)(Eb + (size_t)j * C + 32 * tc + 8 * q + 4 * hi) = v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dxc[tc][4 * q + u] -= v[u];
+            }
+    }
+    if (ok) {
+        float* sb = dxself + ((size_t)cloud * N + p) * C;
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {dxc[tc][4 * q], dxc[tc][4 * q + 1], dxc[tc][4 * q + 2], dxc[tc][4 * q + 3]};
+                *(f32x4*)(sb + 32 * tc + 8 * q + 4 * hi) = v;
+            }
+    }
+}
+
 // dx[t] = sum_slab dxself[slab][t] + sum over the incoming edges e of t (ascending) of sum_slab E[slab][e].
 // One wave per target row, lane = channel (C = 64).   grid (ceil(N / 4), B)
 __global__ __launch_bounds__(256) void edge_gather_kernel(const float* __restrict__ E, const float* __restrict__ dxself,
@@ -454,6 +615,7 @@ extern "C" size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout)
     return (size_t)B * edgeconv_bwd_nwg(N) * 4 * 2 * C * Cout * sizeof(float);
 }
 
+// (the bf16 form sums the slabs before it stores: ask with Cout = 32)
 extern "C" size_t sed_edgeconv_bwd_edge_ws_bytes(int B, int N, int C, int Cout, int k) {
     return (size_t)B * (Cout / 32) * ((size_t)N * k + N) * C * sizeof(float);
 }
@@ -465,12 +627,13 @@ extern "C" size_t sed_edgeconv_bwd_edge_ws_bytes(int B, int N, int C, int Cout, 
 //   * rptr [B,N+1], redge [B,N k] = the reverse graph (edge ids p k + j stably sorted by their target idx[p][j], row t =
 //     redge[rptr[t] .. rptr[t+1])) and edge_ws (sed_edgeconv_bwd_edge_ws_bytes): deterministic -- per-edge contributions
 //     are stored and gathered per target row in ascending edge order; columns 0..63 of dx are overwritten, the rest is left
-//     alone. Up to 4 slabs (Cout <= 128).
+//     alone. Up to 4 slabs (Cout <= 128). bf16 != 0 (deterministic path only): the input-gradient products on the bf16
+//     matrix pipe (edgeconv_bwd_input_bf16_kernel; operands rounded to nearest even, fp32 accumulate).
 extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
                                     const int* idx, const float* W1t, const float* W2t, const float* S,
                                     const uint8_t* jsel, const float* ak, float* dW1t, float* dW2t, float* dx,
                                     int lddx, void* partials, size_t partials_bytes, const int* rptr, const int* redge,
-                                    void* edge_ws, size_t edge_ws_bytes, hipStream_t stream) {
+                                    void* edge_ws, size_t edge_ws_bytes, int bf16, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || k > 255 || !x || !idx || !W1t || !W2t || !S || !jsel || !ak || !dW1t || !dW2t ||
         !partials)
         return SED_EINVAL;
@@ -498,13 +661,30 @@ extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G,
         const dim3 ig((N + 127) / 128, B, Cout / 32);
         if (rptr) {
             if (!redge || !edge_ws || Cout > 128) return SED_EINVAL;
-            if (edge_ws_bytes < sed_edgeconv_bwd_edge_ws_bytes(B, N, C, Cout, k)) return SED_EINVAL;
+            if (edge_ws_bytes < sed_edgeconv_bwd_edge_ws_bytes(B, N, C, bf16 ? 32 : Cout, k)) return SED_EINVAL;
             float* E = (float*)edge_ws;
-            float* dxself = E + (size_t)B * (Cout / 32) * N * k * C;
-            edgeconv_bwd_input_kernel<32, true><<<ig, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, dx,
-                                                                         lddx, N, E, dxself);
-            SED_LAUNCH_CHECK();
-            edge_gather_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(E, dxself, rptr, redge, Cout / 32, N, k, dx, lddx);
+            if (bf16) {
+                float* dxself = E + (size_t)B * N * k * C;
+                const size_t sm = (size_t)(2 * Cout * 72 + 2 * (Cout / 32) * 64 * 40) * 2 + (size_t)4 * 32 * (Cout + 4) * 4;
+                static size_t sm_set = 0;
+                if (sm > sm_set) {
+                    hipError_t e = hipFuncSetAttribute((const void*)edgeconv_bwd_input_bf16_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+                    if (e != hipSuccess) return (int)e;
+                    sm_set = sm;
+                }
+                edgeconv_bwd_input_bf16_kernel<<<dim3((N + 127) / 128, B), 256, sm, stream>>>(
+                    x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, N, E, dxself);
+                SED_LAUNCH_CHECK();
+                edge_gather_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(E, dxself, rptr, redge, 1, N, k, dx, lddx);
+            } else {
+                float* dxself = E + (size_t)B * (Cout / 32) * N * k * C;
+                edgeconv_bwd_input_kernel<32, true><<<ig, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak,
+                                                                             dx, lddx, N, E, dxself);
+                SED_LAUNCH_CHECK();
+                edge_gather_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(E, dxself, rptr, redge, Cout / 32, N, k, dx,
+                                                                             lddx);
+            }
         } else {
             edgeconv_bwd_input_kernel<32, false><<<ig, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak,
                                                                           dx, lddx, N, nullptr, nullptr);

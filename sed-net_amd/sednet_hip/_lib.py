@@ -62,7 +62,7 @@ SIGNATURES = {
     "sed_edgeconv_bwd_partials_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sed_edgeconv_bwd_edge_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sed_edgeconv_bwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P,
-                                     c_int, P, c_size_t, P, P, P, c_size_t, P]),
+                                     c_int, P, c_size_t, P, P, P, c_size_t, c_int, P]),
     "sed_pair_entropy_partials": (c_size_t, [c_int]),
     "sed_pair_entropy_f32": (c_int, [c_int, c_int, P, c_int, c_int, c_float, P, P]),
     "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),

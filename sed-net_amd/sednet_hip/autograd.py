@@ -55,7 +55,8 @@ class EdgeConvGN(torch.autograd.Function):
         k = idx.shape[2]
         S, dgamma, dbeta, ak = ops.gn_bwd_reduce(dout.contiguous(), ysel, Cout, G, float(Cout // G) * N * k, stats, g, b,
                                                  ops.ACT_LEAKY, slope)
-        dW1t, dW2t, dx = ops.edgeconv_bwd(xd, C, idx, W1t, W2t, G, S, jsel, ak, ctx.needs_input_grad[0])
+        dW1t, dW2t, dx = ops.edgeconv_bwd(xd, C, idx, W1t, W2t, G, S, jsel, ak, ctx.needs_input_grad[0],
+                                          bf16=ops.TRAIN_BF16)
         dW = torch.cat([dW1t.t(), dW2t.t()], dim=1).reshape(wshape)
         return dx, None, dW, dgamma, dbeta, None, None, None, None
 

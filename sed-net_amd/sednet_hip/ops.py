@@ -477,7 +477,7 @@ def reverse_graph(idx):
     return rptr, order.int().contiguous()
 
 
-def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=None):
+def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=None, bf16=False):
     """-> (dW1t [C,Cout], dW2t [C,Cout], dx [B,N,ldx] or None)."""
     B, N, ldx = x.shape
     k = idx.shape[2]
@@ -493,12 +493,13 @@ def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=Non
     nws = 0
     if need_dx and det and Cout <= 128:
         rptr, redge = reverse_graph(idx)
-        nws = lib.sed_edgeconv_bwd_edge_ws_bytes(B, N, C, Cout, k)
+        nws = lib.sed_edgeconv_bwd_edge_ws_bytes(B, N, C, 32 if bf16 else Cout, k)      # bf16 kernel: one slab
         ews = torch.empty((nws,), dtype=torch.uint8, device=dev)
     check(lib.sed_edgeconv_bwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(S), ptr(jsel),
                                    ptr(ak), ptr(dW1t), ptr(dW2t), ptr(dx) if need_dx else None, ldx, ptr(part), nb,
                                    ptr(rptr) if rptr is not None else None, ptr(redge) if redge is not None else None,
-                                   ptr(ews) if ews is not None else None, nws, stream()), "edgeconv_bwd")
+                                   ptr(ews) if ews is not None else None, nws, 1 if (bf16 and rptr is not None) else 0,
+                                   stream()), "edgeconv_bwd")
     return dW1t, dW2t, dx
 
 

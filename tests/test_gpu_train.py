@@ -95,6 +95,13 @@ def test_edgeconv_input_gradient_is_deterministic(T, Cout, N, k, B):
     assert T.equal(atom[0], runs[0][0]) and T.equal(atom[1], runs[0][1])              # weight gradients: same kernel
     scale = float(atom[2].abs().max())
     np.testing.assert_allclose(runs[0][2].cpu().numpy(), atom[2].cpu().numpy(), atol=2e-5 * scale)
+    # bf16 products (edgeconv_bwd_input_bf16_kernel: all slabs in one workgroup, one E slab): reproducible, and the fp32
+    # result up to bf16 rounding of W, x_j - x_p and dy (relative 2^-9 each, averaged over 64 / Cout terms)
+    b16 = [ops.edgeconv_bwd(x, C, idx, W1t, W2t, 2, S, jsel, ak, True, deterministic=True, bf16=True) for _ in range(2)]
+    assert T.equal(b16[0][2], b16[1][2])
+    err = (b16[0][2] - runs[0][2]).abs()
+    assert float(err.max()) < 2e-2 * scale and float(err.mean()) < 2e-3 * scale, (float(err.max()) / scale, float(err.mean()) / scale)
+    assert T.equal(b16[0][2][:, :, C:], T.zeros_like(b16[0][2][:, :, C:]))
 
 
 @pytest.mark.parametrize("K,Cout,G,act,N,B,cb", [(256, 512, 8, 1, 333, 2, True), (256, 128, 4, 0, 200, 1, False),

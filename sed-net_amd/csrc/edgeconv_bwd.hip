@@ -19,6 +19,13 @@ namespace {
 
 constexpr int ACT_RELU = 1, ACT_LEAKY = 2;   // 0 = none
 
+typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf(bbf16x8 a, bbf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+
 // ---- S and per-(cloud, chunk, channel) partial sums of dz and dz * yhat ---------------------------------------
 // grid (C/64, B, nchunk), block 256 = 4 row lanes x 64 channels; rows [chunk*256, +256)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ dout, int ldd,
@@ -220,6 +227,165 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_weight_kernel(const float
         }
 }
 
+// ---- EdgeConv weight gradients on the bf16 matrix pipe (TRAIN_BF16; C = 64 layers; round 2) -----------------------
+// Same decomposition as edgeconv_bwd_weight_kernel -- lane = output channel, contraction over points, per-workgroup
+// partials reduced in fixed order -- with v_mfma_f32_32x32x16_bf16 and one gather per edge block instead of one per slab:
+// the NSLAB waves that own the slabs of one 32-point block share the block's difference tile d[p][c] = x_j - x_p (formed in
+// fp32, rounded to bf16 like the forward does) through LDS; each of them gathers 64 / NSLAB channels of it, double
+// buffered, one barrier per neighbour slot j. A wave then reads the tile twice: row-wise (its own point's 8 consecutive
+// channels: the A operand of y = d W1 + base, K = channels) and column-wise (8 points' value of its channel: the A operand
+// of dW1 = d^T dy, K = points, taken in the order the accumulator registers of y hold them, so dy goes into its B operand
+// without leaving the registers). 8 MFMAs of 32 cycles per (edge block, slab) where the fp32 kernel issues 64 of 64 cycles
+// and 32 scalar gathers. W1 / W2 columns of the wave's slab live in registers.
+// grid (nwgx, B), 256 threads: wave w -> slab w % NSLAB of point block (group * PB + w / NSLAB), PB = 4 / NSLAB.
+template <int NSLAB>
+__global__ __launch_bounds__(256, 1) void edgeconv_bwd_weight_bf16_kernel(
+    const float* __restrict__ x, int ldx, const int* __restrict__ idx, int k, const float* __restrict__ W1t,
+    const float* __restrict__ W2t, int G, const float* __restrict__ S, const uint8_t* __restrict__ jsel,
+    const float* __restrict__ ak, float* __restrict__ part, int N) {
+    constexpr int C = 64, Cout = 32 * NSLAB, PB = 4 / NSLAB, LDT = 72 /* bf16 per tile row: 144 B */;
+    constexpr int CPW = C / NSLAB;                         // channels of the tile a wave gathers
+    __shared__ __attribute__((aligned(16))) __bf16 dtile[2][PB][32 * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 xtile[PB][32 * LDT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int slab = wave % NSLAB, sb = wave / NSLAB, o0 = 32 * slab;
+    const int cloud = blockIdx.y;
+    const float* xb = x + (size_t)cloud * N * ldx;
+    const int g = o0 / (Cout / G);
+    const float alpha = ak[((size_t)cloud * G + g) * 2], kappa = ak[((size_t)cloud * G + g) * 2 + 1];
+
+    // B operands of y: W[c = 16 t + 8 hi + i][o = o0 + li]
+    bbf16x8 w1r[4], w2r[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            w1r[t][i] = (__bf16)W1t[(size_t)(16 * t + 8 * hi + i) * Cout + o0 + li];
+            w2r[t][i] = (__bf16)W2t[(size_t)(16 * t + 8 * hi + i) * Cout + o0 + li];
+        }
+    f32x16 dW1[2], dW2[2];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW1[tc][r] = 0.f; dW2[tc][r] = 0.f; }
+
+    // column-wise tile read: this lane's channel 32 tc + li of points row(8 u + i, hi), i = 0..7
+    auto read_T = [&](const __bf16* tile, int tc, int u) {
+        bbf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = tile[((i & 3) + 16 * u + 8 * (i >> 2) + 4 * hi) * LDT + 32 * tc + li];
+        return a;
+    };
+
+    const int nblk = (N + 31) / 32, ngrp = (nblk + PB - 1) / PB;
+    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+        const int pb = grp * PB + sb;
+        const int p0 = pb * 32;
+        const int p = p0 + li, pc = p < N ? p : N - 1;
+        const int* ib = idx + ((size_t)cloud * N + pc) * k;
+        // this wave's channel slice of its point's row (fp32, kept for the differences) and of the x tile
+        float xs[CPW / 2];
+#pragma unroll
+        for (int q = 0; q < CPW / 16; ++q) {
+            const int c0 = CPW * slab + 16 * q + 8 * hi;
+            const f32x4 a = *(const f32x4*)(xb + (size_t)pc * ldx + c0);
+            const f32x4 b = *(const f32x4*)(xb + (size_t)pc * ldx + c0 + 4);
+            bbf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xs[8 * q + i] = a[i]; xs[8 * q + 4 + i] = b[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (__bf16)xs[8 * q + i];
+            *(bbf16x8*)(&xtile[sb][li * LDT + c0]) = v;
+        }
+        f32x4 nx[CPW / 8];
+        auto gather = [&](int j) {
+            const int nb = ib[j];
+#pragma unroll
+            for (int q = 0; q < CPW / 16; ++q) {
+                const int c0 = CPW * slab + 16 * q + 8 * hi;
+                nx[2 * q] = *(const f32x4*)(xb + (size_t)nb * ldx + c0);
+                nx[2 * q + 1] = *(const f32x4*)(xb + (size_t)nb * ldx + c0 + 4);
+            }
+        };
+        auto put = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < CPW / 16; ++q) {
+                bbf16x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (__bf16)((i < 4 ? nx[2 * q][i] : nx[2 * q + 1][i - 4]) - xs[8 * q + i]);
+                *(bbf16x8*)(&dtile[buf][sb][li * LDT + CPW * slab + 16 * q + 8 * hi]) = v;
+            }
+        };
+        gather(0);
+        // per accumulator register r: point row(r, hi), channel o0 + li
+        float Sr[16];
+        unsigned jsp[4] = {0u, 0u, 0u, 0u};
+        unsigned vmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = p0 + mfma_row(r, hi);
+            const bool okr = row < N;
+            vmask |= (okr ? 1u : 0u) << r;
+            const size_t o = ((size_t)cloud * N + (okr ? row : N - 1)) * Cout + o0 + li;
+            Sr[r] = okr ? S[o] : 0.f;
+            jsp[r >> 2] |= (okr ? (unsigned)jsel[o] : 0xffu) << (8 * (r & 3));     // 255 never equals j (k <= 255)
+        }
+        put(0);
+        __syncthreads();                                   // x tile and difference tile 0 complete
+        f32x16 base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            base = mfma_bf(*(const bbf16x8*)(&xtile[sb][li * LDT + 16 * t + 8 * hi]), w2r[t], base);
+        float dysum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dysum[r] = 0.f;
+
+        for (int j = 0; j < k; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < k) gather(j + 1);
+            const __bf16* tile = dtile[cur][sb];
+            f32x16 acc = base;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc = mfma_bf(*(const bbf16x8*)(tile + li * LDT + 16 * t + 8 * hi), w1r[t], acc);
+            bbf16x8 dyB[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float dy = (vmask >> r) & 1u ? fmaf(kappa, acc[r], alpha) : 0.f;
+                dy += (int)((jsp[r >> 2] >> (8 * (r & 3))) & 0xffu) == j ? Sr[r] : 0.f;
+                dysum[r] += dy;
+                dyB[r >> 3][r & 7] = (__bf16)dy;
+            }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) dW1[tc] = mfma_bf(read_T(tile, tc, u), dyB[u], dW1[tc]);
+            if (j + 1 < k) put(cur ^ 1);
+            __syncthreads();
+        }
+        bbf16x8 dsB[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsB[r >> 3][r & 7] = (__bf16)dysum[r];
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) dW2[tc] = mfma_bf(read_T(xtile[sb], tc, u), dsB[u], dW2[tc]);
+        __syncthreads();                                   // before the next group overwrites the tiles
+    }
+    // partials: part[cloud][wg][sb][2][C][Cout]; the NSLAB waves of a point block fill disjoint columns of one slot
+    float* pw = part + ((((size_t)cloud * gridDim.x + blockIdx.x) * PB + sb) * 2) * C * Cout;
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = 32 * tc + mfma_row(r, hi);
+            pw[(size_t)c * Cout + o0 + li] = dW1[tc][r];
+            pw[(size_t)(C + c) * Cout + o0 + li] = dW2[tc][r];
+        }
+}
+
 // sum the weight partials in fixed order.  grid ceil(2*C*Cout/256)
 __global__ void edgeconv_bwd_weight_reduce_kernel(const float* __restrict__ part, int nslot, size_t stride, int n,
                                                   float* __restrict__ dW) {
@@ -380,12 +546,6 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_kernel(const float*
 // re-reads the point's 16 values), jsel comes from global memory. The edge contribution df (summed over slabs here, so E
 // has ONE slab: a quarter of the fp32 kernel's traffic at Cout = 128) and the self term are stored straight from the
 // accumulator layout, 16 bytes per lane and store, into the rows the gather kernel reads.  grid (ceil(N/128), B)
-typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x16 mfma_bf(bbf16x8 a, bbf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 __global__ __launch_bounds__(256, 1) void edgeconv_bwd_input_bf16_kernel(
     const float* __restrict__ x, int ldx, const int* __restrict__ idx, int k, const float* __restrict__ W1t,
     const float* __restrict__ W2t, int Cout, int G, const float* __restrict__ S, const uint8_t* __restrict__ jsel,
@@ -627,8 +787,10 @@ extern "C" size_t sed_edgeconv_bwd_edge_ws_bytes(int B, int N, int C, int Cout, 
 //   * rptr [B,N+1], redge [B,N k] = the reverse graph (edge ids p k + j stably sorted by their target idx[p][j], row t =
 //     redge[rptr[t] .. rptr[t+1])) and edge_ws (sed_edgeconv_bwd_edge_ws_bytes): deterministic -- per-edge contributions
 //     are stored and gathered per target row in ascending edge order; columns 0..63 of dx are overwritten, the rest is left
-//     alone. Up to 4 slabs (Cout <= 128). bf16 != 0 (deterministic path only): the input-gradient products on the bf16
-//     matrix pipe (edgeconv_bwd_input_bf16_kernel; operands rounded to nearest even, fp32 accumulate).
+//     alone. Up to 4 slabs (Cout <= 128).
+// bf16 != 0 (C = 64, Cout = 64 / 128): weight-gradient products on the bf16 matrix pipe (edgeconv_bwd_weight_bf16_kernel) and,
+// with the reverse graph, the input-gradient products too (edgeconv_bwd_input_bf16_kernel); operands rounded to nearest
+// even, fp32 accumulate, the same fixed-order reductions.
 extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
                                     const int* idx, const float* W1t, const float* W2t, const float* S,
                                     const uint8_t* jsel, const float* ak, float* dW1t, float* dW2t, float* dx,
@@ -642,7 +804,20 @@ extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G,
     const int nwg = edgeconv_bwd_nwg(N);
     float* part = (float*)partials;
     dim3 grid(nwg, B, Cout / 32);
-    if (C == 6)
+    int nslot = B * nwg * 4;
+    if (bf16 && C == 64 && (Cout == 64 || Cout == 128)) {
+        // slots = workgroups x point blocks per workgroup <= 64 per cloud = the buffer sed_edgeconv_bwd_partials_bytes sizes
+        const int PB = 4 / (Cout / 32), ngrp = ((N + 31) / 32 + PB - 1) / PB;
+        int nwgx = 4 * nwg / PB;
+        if (nwgx > ngrp) nwgx = ngrp;
+        if (Cout == 128)
+            edgeconv_bwd_weight_bf16_kernel<4><<<dim3(nwgx, B), 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, G, S, jsel, ak,
+                                                                                  part, N);
+        else
+            edgeconv_bwd_weight_bf16_kernel<2><<<dim3(nwgx, B), 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, G, S, jsel, ak,
+                                                                                  part, N);
+        nslot = B * nwgx * PB;
+    } else if (C == 6)
         edgeconv_bwd_weight_kernel<3><<<grid, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, part, N);
     else if (C == 64)
         edgeconv_bwd_weight_kernel<32><<<grid, 256, 0, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, G, S, jsel, ak, part, N);
@@ -651,7 +826,6 @@ extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G,
     SED_LAUNCH_CHECK();
     // partial layout [slot][2][C][Cout]
     const int n = C * Cout;
-    const int nslot = B * nwg * 4;
     edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part, nslot, (size_t)2 * n, n, dW1t);
     SED_LAUNCH_CHECK();
     edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part + n, nslot, (size_t)2 * n, n, dW2t);

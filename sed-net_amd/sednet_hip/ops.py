@@ -498,7 +498,7 @@ def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=Non
     check(lib.sed_edgeconv_bwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(S), ptr(jsel),
                                    ptr(ak), ptr(dW1t), ptr(dW2t), ptr(dx) if need_dx else None, ldx, ptr(part), nb,
                                    ptr(rptr) if rptr is not None else None, ptr(redge) if redge is not None else None,
-                                   ptr(ews) if ews is not None else None, nws, 1 if (bf16 and rptr is not None) else 0,
+                                   ptr(ews) if ews is not None else None, nws, 1 if bf16 else 0,
                                    stream()), "edgeconv_bwd")
     return dW1t, dW2t, dx
 

@@ -102,6 +102,11 @@ def test_edgeconv_input_gradient_is_deterministic(T, Cout, N, k, B):
     err = (b16[0][2] - runs[0][2]).abs()
     assert float(err.max()) < 2e-2 * scale and float(err.mean()) < 2e-3 * scale, (float(err.max()) / scale, float(err.mean()) / scale)
     assert T.equal(b16[0][2][:, :, C:], T.zeros_like(b16[0][2][:, :, C:]))
+    for a, b_, f in zip(b16[0][:2], b16[1][:2], runs[0][:2]):                          # weight gradients (bf16 kernel)
+        assert T.equal(a, b_)
+        e = (a - f).abs()
+        sc = float(f.abs().max())
+        assert float(e.max()) < 2e-2 * sc and float(e.mean()) < 3e-3 * sc, (float(e.max()) / sc, float(e.mean()) / sc)
 
 
 @pytest.mark.parametrize("K,Cout,G,act,N,B,cb", [(256, 512, 8, 1, 333, 2, True), (256, 128, 4, 0, 200, 1, False),

@@ -347,7 +347,7 @@ def test_bf16_layers_equal_fp32_layers_on_rounded_operands(T):
 
 
 def test_bf16_training_tracks_fp32(T):
-    """BASELINE configs[4] in small: 30 AdamW steps on one synthetic batch in fp32 and with bf16 products, same
+    """BASELINE configs[4] in small: 50 AdamW steps on one synthetic batch in fp32 and with bf16 products, same
     initial weights and the same triplet draws: the two loss curves stay together and both go down."""
     from sednet_hip import ops, synth
     from sednet_hip.train import train_step
@@ -361,7 +361,7 @@ def test_bf16_training_tracks_fp32(T):
             m = _model(T, 20, 3)
             opt = T.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
             hist = []
-            for it in range(30):
+            for it in range(50):
                 np.random.seed(5)
                 hist.append(train_step(m, opt, batch, smoothing=0.025)["loss"])
             curves[bf16] = np.array(hist)

@@ -7,8 +7,11 @@ caller is Fitting_patches_and_edges/residual_utils.py:86-331:
     guard_mean_shift(quantile 0.015, 50 iterations, x1.2 while > 49 clusters)   :25-35, :382
     per segment: type vote (stats.mode) -> LSQ fit -> closed-form residual     residual_utils.py:259, :300-331
 
-B clouds go through every stage in one launch each; the only host syncs are the guard loop's cluster counts
-(one small D->H copy per pass, as in the reference :31).
+B clouds go through every stage in one launch each. Host syncs per step, all of them copies of a few bytes per cloud: the
+overflow flags of the five streaming kNN calls (ops.knn_features / knn_points_normals: a raised flag re-runs the exact
+path), and per guard pass the bandwidth kernel's per-cloud overflow flags, the density probe that picks the mean-shift
+schedule (ops.ms_near_fraction) and the cluster counts the guard loop branches on (the reference's :31; it syncs at least
+three times per CLOUD and pass, plus a numpy round trip).
 """
 import torch
 

@@ -293,6 +293,42 @@ def test_fused_kth_distance_is_bit_identical(T, N, d, K, B):
                 assert K2 > 160
 
 
+@pytest.mark.parametrize("N", [1024, 2047, 16384])
+def test_block_sparse_split_fp16_edges(T, N):
+    """Sizes at the ends of the block-sparse kernel's range (32 .. 512 stages, ragged last stage, one or several reference
+    groups), a cloud with non-unit rows in the batch (flagged by the split kernel: the exact dense fp32 kernel takes it, the
+    others stay sparse), zero iterations, and the size limit."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import lib
+    Xs = np.stack([synth.clustered_embedding(N=N, d=128, n_clusters=7 + 3 * c, sigma=0.01, seed=200 + c)[0] for c in range(3)])
+    Xs[1] *= np.float32(1.03)
+    X = dev(T, Xs)
+    bw = T.full((3,), 0.15, device="cuda")
+    try:
+        ops.ms_set_variant("batched")
+        exact = ops._ms_iterate_dense(X, bw, 6).cpu().numpy()
+        ops.ms_set_variant("f16")
+        dense = ops._ms_iterate_dense(X, bw, 6).cpu().numpy()
+    finally:
+        ops.ms_set_variant("auto")
+    stats = T.zeros(5, dtype=T.int64, device="cuda")
+    got = ops.ms_iterate_sparse(X, bw, 6, stats=stats).cpu().numpy()
+    np.testing.assert_allclose(got[[0, 2]], dense[[0, 2]], atol=3e-6)
+    np.testing.assert_allclose(got[1], exact[1], atol=2e-5)                  # the flagged cloud: fp32 kernel on the sorted rows
+    st = stats.cpu().numpy()
+    nwg = (N + 255) // 256
+    assert st[3] == 2 * nwg * 8 * ((N + 31) // 32) * 6                       # two clouds ran the sparse kernel
+    assert st[1] < 0.6 * st[3]
+    np.testing.assert_array_equal(ops.ms_iterate_sparse(X, bw, 0).cpu().numpy(), Xs)      # 0 iterations: the rows themselves
+    assert lib.sed_ms_iterate_bounds_f16_refs(N) == 64 * (((N + 31) // 32 + 31) // 32)
+    if N == 16384:
+        Xb = T.nn.functional.normalize(T.randn(1, 16416, 128, generator=T.Generator().manual_seed(3)), dim=2).cuda()
+        # 513 stages: beyond the bounds kernels; a forced sparse call takes the fp32 first-level kernel, "auto" stays dense
+        d1 = ops._ms_iterate_dense(Xb, bw[:1], 1).cpu().numpy()
+        np.testing.assert_allclose(ops.ms_iterate_sparse(Xb, bw[:1], 1).cpu().numpy(), d1, atol=2e-5)
+        np.testing.assert_array_equal(ops.ms_iterate(Xb, bw[:1], 1).cpu().numpy(), d1)
+
+
 def test_farthest_point_pivots_kernel(T):
     """sed_fps_pivots_f32 (all greedy steps in one launch) against the step-by-step host loop on the same candidates: the
     same picks wherever the arg-min is not a near-tie, the same k-centre radius at every step count checked."""

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void fps_pivots_kernel(const float* __restric
             int bi = red_i[0];
             for (int w = 1; w < 16; ++w)
                 if (red_v[w] < bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
-            cur = bi;
+            cur = bi < Ns ? bi : 0;                        // rows with NaN never compare smaller: stay inside the cloud
         }
         __syncthreads();
     }

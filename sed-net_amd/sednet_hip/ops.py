@@ -194,7 +194,8 @@ def ms_near_fraction(X, bw, skip_below=-30.0, rows=64, keys=512):
     qi, ki = _PROBE_IDX[key]
     dist = 2.0 - 2.0 * torch.bmm(X[:, qi], X[:, ki].transpose(1, 2))
     thr = (-2.0 * skip_below) * bw * bw
-    return (dist < thr.view(B, 1, 1)).float().mean((1, 2))
+    frac = (dist < thr.view(B, 1, 1)).float().mean((1, 2))
+    return torch.where(torch.isfinite(dist).all(2).all(1), frac, torch.ones_like(frac))     # NaN / inf rows: dense path
 
 
 def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):

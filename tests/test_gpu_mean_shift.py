@@ -329,6 +329,26 @@ def test_block_sparse_split_fp16_edges(T, N):
         np.testing.assert_array_equal(ops.ms_iterate(Xb, bw[:1], 1).cpu().numpy(), d1)
 
 
+def test_nan_cloud_does_not_derail_the_sparse_path(T):
+    """A cloud with NaN rows next to clustered clouds: the density probe sends it to the dense path ("auto"); forced through
+    the sparse path the pivot kernel stays inside the cloud (NaN never compares smaller), the split kernel flags it and the
+    dense fp32 kernel returns NaN rows for it -- the other clouds get their usual rows either way."""
+    from sednet_hip import ops, synth
+    Xs = np.stack([synth.clustered_embedding(N=4096, d=128, n_clusters=9 + c, sigma=0.01, seed=300 + c)[0] for c in range(3)])
+    Xs[1, 100:110] = np.nan
+    X = dev(T, Xs)
+    bw = T.full((3,), 0.15, device="cuda")
+    assert ops.ms_near_fraction(X, bw).cpu().numpy()[1] == 1.0
+    good = ops.ms_iterate(X[[0, 2]].contiguous(), bw[[0, 2]].contiguous(), 5).cpu().numpy()
+    ops.MS_SPARSE_STATS.update(sparse_clouds=0, dense_clouds=0)
+    auto = ops.ms_iterate(X, bw, 5).cpu().numpy()
+    assert ops.MS_SPARSE_STATS == {"sparse_clouds": 2, "dense_clouds": 1}
+    forced = ops.ms_iterate_sparse(X, bw, 5).cpu().numpy()
+    for got in (auto, forced):
+        np.testing.assert_allclose(got[[0, 2]], good, atol=3e-6)
+        assert np.isnan(got[1]).any()
+
+
 def test_farthest_point_pivots_kernel(T):
     """sed_fps_pivots_f32 (all greedy steps in one launch) against the step-by-step host loop on the same candidates: the
     same picks wherever the arg-min is not a near-tie, the same k-centre radius at every step count checked."""

@@ -386,14 +386,17 @@ __global__ __launch_bounds__(256, 1) void edgeconv_bwd_weight_bf16_kernel(
         }
 }
 
-// sum the weight partials in fixed order.  grid ceil(2*C*Cout/256)
-__global__ void edgeconv_bwd_weight_reduce_kernel(const float* __restrict__ part, int nslot, size_t stride, int n,
-                                                  float* __restrict__ dW) {
+// sum the weight partials in fixed order, two levels: grid (ceil(n / 256), nchunk) sums slots [chunk * per, +per) into
+// out[chunk][n] (fp64 accumulate, fp32 store when it is the last level); the second launch (nchunk = 1) sums the chunks.
+// (One level -- every thread walking all 2048 slots -- kept only n / 256 = 32 workgroups busy: 0.6 ms per call.)
+__global__ void edgeconv_bwd_weight_reduce_kernel(const float* __restrict__ part, int nslot, size_t stride, int n, int per,
+                                                  float* __restrict__ out, size_t ostride) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int s0 = blockIdx.y * per, s1 = min(nslot, s0 + per);
     double a = 0.0;
-    for (int s = 0; s < nslot; ++s) a += (double)part[(size_t)s * stride + i];
-    dW[i] = (float)a;
+    for (int s = s0; s < s1; ++s) a += (double)part[(size_t)s * stride + i];
+    out[(size_t)blockIdx.y * ostride + i] = (float)a;
 }
 
 // ---- EdgeConv: input gradients -------------------------------------------------------------------------------
@@ -772,7 +775,8 @@ static int edgeconv_bwd_nwg(int N) {
 }
 
 extern "C" size_t sed_edgeconv_bwd_partials_bytes(int B, int N, int C, int Cout) {
-    return (size_t)B * edgeconv_bwd_nwg(N) * 4 * 2 * C * Cout * sizeof(float);
+    const size_t nslot = (size_t)B * edgeconv_bwd_nwg(N) * 4;                 // + the chunk sums of the two-level reduction
+    return (nslot + (nslot + 31) / 32) * 2 * C * Cout * sizeof(float);
 }
 
 // (the bf16 form sums the slabs before it stores: ask with Cout = 32)
@@ -826,9 +830,18 @@ extern "C" int sed_edgeconv_bwd_f32(int B, int N, int C, int Cout, int k, int G,
     SED_LAUNCH_CHECK();
     // partial layout [slot][2][C][Cout]
     const int n = C * Cout;
-    edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part, nslot, (size_t)2 * n, n, dW1t);
+    // level 1: chunks of 32 slots -> the head of the (now consumed) partial buffer is NOT reusable while it is being read, so
+    // the chunk sums go behind the last slot; sed_edgeconv_bwd_partials_bytes reserves that room
+    const int per = 32, nchunk = (nslot + per - 1) / per;
+    float* lvl = part + (size_t)nslot * 2 * n;
+    edgeconv_bwd_weight_reduce_kernel<<<dim3((2 * n + 255) / 256, nchunk), 256, 0, stream>>>(part, nslot, (size_t)2 * n, 2 * n,
+                                                                                            per, lvl, (size_t)2 * n);
     SED_LAUNCH_CHECK();
-    edgeconv_bwd_weight_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(part + n, nslot, (size_t)2 * n, n, dW2t);
+    edgeconv_bwd_weight_reduce_kernel<<<dim3((n + 255) / 256, 1), 256, 0, stream>>>(lvl, nchunk, (size_t)2 * n, n, nchunk,
+                                                                                   dW1t, 0);
+    SED_LAUNCH_CHECK();
+    edgeconv_bwd_weight_reduce_kernel<<<dim3((n + 255) / 256, 1), 256, 0, stream>>>(lvl + n, nchunk, (size_t)2 * n, n, nchunk,
+                                                                                   dW2t, 0);
     SED_LAUNCH_CHECK();
     if (dx) {
         if (C != 64 || lddx < C) return SED_EUNSUPPORTED;

@@ -27,6 +27,8 @@ def _as_bw_tensor(b, B, device):
 
 
 class MeanShift:
+    match_rng = False          # batched calls: replay the reference's per-cloud np.random.shuffle even when it cannot matter
+
     def __init__(self):
         pass
 
@@ -88,7 +90,18 @@ class MeanShift:
         Xp = ops.pad_features(X)
         if bw is None:
             K = int(quantile * num_samples)
-            Xs = Xp if num_samples >= N else Xp[:, self._subset(N, num_samples, X.device)]
+            if num_samples >= N:
+                # every row is kept: the statistic does not depend on the order. The reference still consumes one
+                # np.random.shuffle per cloud here (mean_shift.py:126-128); `match_rng` replays that (0.15 ms of host time
+                # per cloud and pass) for callers that share the global numpy stream with other code
+                if self.match_rng:
+                    for _ in range(B):
+                        self._subset(N, num_samples, "cpu")
+                Xs = Xp
+            else:
+                # one subset per cloud, drawn cloud by cloud like the reference's per-cloud calls
+                sub = torch.stack([self._subset(N, num_samples, X.device) for _ in range(B)])
+                Xs = torch.gather(Xp, 1, sub.unsqueeze(-1).expand(B, num_samples, Xp.shape[2]))
             bw = ops.ms_bandwidth(Xs.contiguous(), K, 0.003)
         new_Xp = ops.ms_iterate(Xp, bw, iterations)
         labels, ids, n_c, n_l = ops.ms_nms(new_Xp, Xp, bw)

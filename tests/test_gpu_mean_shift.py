@@ -415,6 +415,33 @@ def test_guard_loop_matches_golden(T, golden):
     np.testing.assert_array_equal(canon(labels[0].cpu().numpy()), canon(g["guard_labels"]))
 
 
+def test_batched_bandwidth_draws_like_per_cloud_calls(T):
+    """num_samples < N: the batched call draws one row subset per cloud, cloud by cloud -- the same np.random stream and the
+    same bandwidths as the reference-style per-cloud calls. num_samples >= N: nothing depends on the draw; `match_rng`
+    replays the reference's shuffles anyway so that the global numpy stream ends where the reference leaves it."""
+    from src.mean_shift import MeanShift
+    from sednet_hip import synth
+    ms = MeanShift()
+    Xb = dev(T, np.stack([synth.clustered_embedding(N=1500, d=128, n_clusters=6 + i, sigma=0.02, seed=70 + i)[0] for i in range(3)]))
+    np.random.seed(3)
+    bw_b = ms.mean_shift_batch(Xb, 1000, 0.05, 1)[1].cpu().numpy()
+    after_b = np.random.rand()
+    np.random.seed(3)
+    bw_s = np.array([float(ms.compute_bandwidth(Xb[i], 1000, 0.05)) for i in range(3)])
+    after_s = np.random.rand()
+    np.testing.assert_array_equal(bw_b, bw_s.astype(np.float32))
+    assert after_b == after_s
+    ms2 = MeanShift()
+    ms2.match_rng = True
+    np.random.seed(4)
+    bw_all = ms2.mean_shift_batch(Xb, 1500, 0.05, 1)[1].cpu().numpy()
+    after_all = np.random.rand()
+    np.random.seed(4)
+    bw_ref = np.array([float(ms.compute_bandwidth(Xb[i], 1500, 0.05)) for i in range(3)])
+    assert after_all == np.random.rand()
+    np.testing.assert_array_equal(bw_all, bw_ref.astype(np.float32))
+
+
 def test_batched_equals_single(T, golden):
     from src.mean_shift import MeanShift
     from sednet_hip import synth

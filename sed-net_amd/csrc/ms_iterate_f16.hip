@@ -21,12 +21,14 @@
 // One workgroup = 256 query rows (8 waves x 32) x all keys x all iterations; Q lives in registers as MFMA B operands,
 // the O^T accumulator layout is the Q operand layout of the next iteration (as in ms_iterate.hip).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Stage image for KT keys (KT = 64: 70 KiB, one 8-wave workgroup per CU; KT = 32: 37 KiB, two 4-wave workgroups per CU)
 template <int KT_>
@@ -562,6 +564,333 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Software-pipelined schedule (default since the end of round 2): the exponentials and fp16 splits of block n are issued
+// BETWEEN the MFMAs of block n + 1's first product, inside the same wave; then block n's second product. Same stage images,
+// same three LDS buffers, same operand ring and the same MFMA order per accumulator as ms_iterate_d128_f16p_kernel (hence
+// the same bits); one barrier per block, placed after step 13 of the second product (the last step that still loads from
+// the block's buffer), after which block n + 3 is copied into that buffer.
+#ifndef F16Q_RING_DISTANCE
+#define F16Q_RING_DISTANCE 2
+#endif
+template <bool CHUNKED = false>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int RD = F16Q_RING_DISTANCE;                // the operand ring runs RD steps ahead
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
+    const int nst = (N + 31) >> 5;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 4 w .. 4 w + 3 through the instruction's immediate
+    // offset (it applies to the global and to the LDS address alike), waves 0-4 also piece 32 + w; scalar bases + one
+    // per-lane 32-bit offset, no per-piece address registers
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once
+    int st_cur = s0, st_dma = s0;
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(s0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);
+    if (total > 2) stage_dma(st_dma, 2);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    h16x8 fa[4], fb[4];
+    // Per-lane LDS offsets of the operand reads. They are loop invariants, and the register allocator keeps invariants that
+    // live across the (register-hungry) row update in scratch, reloading them in the hot loop -- where a reload's vmcnt wait
+    // also waits for the stage DMA issued moments earlier. So they are recomputed per block from a lane id the compiler
+    // cannot hoist (5 VALU instructions per block).
+    int xoff = li * XROW + hi * 16;
+    int toff = li * TROW + hi * 16;
+    auto refresh_offsets = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        xoff = (l & 31) * XROW + (l >> 5) * 16;
+        toff = (l & 31) * TROW + (l >> 5) * 16;
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+    // first product of a block outside the pipeline (first block of the launch and of every sweep: Q has just changed),
+    // operands read directly; same MFMA order as the pipelined form -> same bits
+    auto plain_first_product = [&](const uint8_t* base) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+            s = mfma16(l, qh[t], s);
+            s = mfma16(a, ql[t], s);
+            s = mfma16(a, qh[t], s);
+        }
+        return s;
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % 3
+    i32x4 phv[2], plv[2];                                 // weights of the current block: two accumulator rows (fp16 pair) per dword
+    f32x16 s_cur;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+    if (total > 0) s_cur = plain_first_product(lds);
+    if (total > 1) {
+#pragma unroll
+        for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
+    }
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const uint8_t* n2base = lds + (nbuf == 2 ? 0 : nbuf + 1) * STAGE;
+        const int key0 = st_cur * 32;
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
+        const bool has_next = n + 1 < total && !sweep_end;
+        const bool tail = key0 + 32 > N;
+        refresh_offsets();
+
+        // weights of block n from s_cur, two accumulator rows at a time; TAIL: the cloud's last, partly filled stage
+        auto weights2 = [&](int t, auto tail_c) {
+            float p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * t + u;
+                p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
+                if (decltype(tail_c)::value && key0 + mfma_row(r, hi) >= N) p[u] = 0.f;
+                rsum += p[u];
+            }
+            const h16x2 h = {(h16)p[0], (h16)p[1]};
+            const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+            phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+        };
+
+        // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
+        // (Measured on gfx950, tools/micro/mfma_valu_overlap.hip: VALU work of ANOTHER wave of the SIMD does not run under
+        // a wave's MFMAs -- 94 % of the serial time -- while independent VALU instructions interleaved into the SAME wave's
+        // MFMA stream do; the earlier schedules, staggered or not, ran matrix and vector phases back to back.)
+        f32x16 s_next;
+        auto phase1 = [&](auto tail_c) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_next = mfma16(fb[0], qh[0], z);
+                } else {
+                    s_next = mfma16(fb[t & 3], qh[t], s_next);
+                }
+                weights2(t, tail_c);
+                s_next = mfma16(fa[t & 3], ql[t], s_next);
+                s_next = mfma16(fa[t & 3], qh[t], s_next);
+                if (t + RD < 8) ring_load(t + RD, nbase);
+                else ring_load(t + RD, base);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_next) {
+            if (tail) phase1(std::true_type{});
+            else phase1(std::false_type{});
+        } else {                                          // last block of a sweep / of the launch: nothing to overlap with
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (tail) weights2(t, std::true_type{});
+                else weights2(t, std::false_type{});
+                if (t + RD >= 8) ring_load(t + RD, base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- phase 2: second product of block n. After step 13 nobody reads buffer n any more and everybody's pieces of
+        // block n + 2 (issued a block ago) have landed: barrier, then block n + 3 -> buffer n, and the ring moves on to
+        // block n + 2's first-product operands.
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
+            const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+            o[c] = mfma16(fb[t & 3], phj, o[c]);
+            o[c] = mfma16(fa[t & 3], plj, o[c]);
+            o[c] = mfma16(fa[t & 3], phj, o[c]);
+            if (t + RD < 16) ring_load(t + RD, base);
+            else if (n + 2 < total) ring_load(t + RD - 16, n2base);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 15 - RD) {                            // the last step that loads from this block's buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (n + 3 < total) stage_dma(st_dma, buf);
+                advance(st_dma, fwd_dma);
+            }
+        }
+
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (!sweep_end) {
+            s_cur = s_next;
+            continue;
+        }
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (n == total - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm, o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+            s_cur = plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
+        }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Block-sparse schedule on the pipelined split-fp16 kernel (round 2; the fp32 version is ms_sparse.hip).
 // Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure, together with two unit reference
 // vectors per tile (normalised means of two groups of its rows) and cos(alpha) of each, alpha = the widest angle between
@@ -966,8 +1295,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
-// cfg 0: pipelined 8-wave kernel, wave groups half a block out of phase (default); 1: the same, groups in phase;
-// 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave workgroups per CU
+// cfg 0: software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1; default);
+// 1: round-2 pipelined kernel, wave groups in phase; 4: the same, groups half a block out of phase (the default until the
+// software-pipelined kernel); 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave
+// workgroups per CU
 int g_ms_f16_cfg = 0;
 
 static size_t f16_blob_bytes(int B, int N, int cfg) {
@@ -1024,6 +1355,27 @@ static int f16p_launch(int B, int N, int iters, const float* bw, const float* X,
     return SED_OK;
 }
 
+static int f16q_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16q_kernel<false><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N,
+                                                                                                 iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
 // key-chunked split-fp16 schedule: chunk count from N only (results do not depend on how many clouds share a launch):
 // as many chunks as fill the 256 CUs with ONE cloud's workgroups, at least 8 stages per chunk; 0 = not worth it
 int ms_f16_chunks(int N) {
@@ -1059,11 +1411,18 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<true, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
+        if (g_ms_f16_cfg == 0)
+            ms_iterate_d128_f16q_kernel<true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        else
         ms_iterate_d128_f16p_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
             X, blob, newX, bw, flags, N, 1, Q, partO, partS);
         const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, stream);
@@ -1083,7 +1442,8 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     if (e != hipSuccess) return (int)e;
     if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
-    return g_ms_f16_cfg == 0 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
+    if (g_ms_f16_cfg == 0) return f16q_launch(B, N, iters, bw, X, newX, blob, flags, stream);
+    return g_ms_f16_cfg == 4 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
                              : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
 }
 
@@ -1131,7 +1491,7 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 3) return SED_EINVAL;
+    if (cfg < 0 || cfg > 4) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

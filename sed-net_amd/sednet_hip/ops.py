@@ -375,11 +375,12 @@ def _ms_iterate_dense(X, bw, iters):
 
 def ms_set_variant(variant):
     """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
-    "f16" (split-fp16 MFMA emulation, pipelined kernel; "f16c" = its key-chunked form for few clouds per call, "f16i" =
-    wave groups in phase, "f16v1" / "f16b" = the first, unpipelined version with 64-key / 32-key stages)."""
+    "f16" (split-fp16 MFMA emulation, software-pipelined kernel; "f16c" = its key-chunked form for few clouds per call,
+    "f16g" / "f16i" = the earlier pipelined kernel with wave groups half a block out of phase / in phase, "f16v1" / "f16b" =
+    the first, unpipelined version with 64-key / 32-key stages)."""
     global _MS_VARIANT
     _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
-    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3}.get(variant, 0)), "ms_set_f16_config")
+    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4}.get(variant, 0)), "ms_set_f16_config")
     check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5}.get(variant, 4)),
           "ms_set_variant")
 

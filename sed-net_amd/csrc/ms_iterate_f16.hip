@@ -912,6 +912,9 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
 // The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
 // direction so that an iteration starts on the stages the previous one left in L2.
 // What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
+#ifndef F16S_NBUF
+#define F16S_NBUF 3                                    // stage buffers of the sparse kernel (4 fit -- 4 x 37 KiB + 7 KiB of tables <= 160 KiB -- and change nothing: 51.1 vs 50.5 ms)
+#endif
 constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
 
 constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
     constexpr int MAXW = F16S_MAXW;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [F16S_NBUF][STAGE]
     __shared__ unsigned long long wmask[8][MAXW];
     __shared__ int slist[512];
     __shared__ int wcount[8];
@@ -1132,6 +1135,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
         if (ns > 0) stage_dma(entry(0), 0);
         if (ns > 1) stage_dma(entry(1), 1);
+        if (F16S_NBUF > 3 && ns > 2) stage_dma(entry(2), 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ns > 0) {
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         int buf = 0;
         for (int j = 0; j < ns; ++j) {
             const uint8_t* base = lds + buf * STAGE;
-            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const int nbuf = buf == F16S_NBUF - 1 ? 0 : buf + 1;
             const uint8_t* nbase = lds + nbuf * STAGE;
             const int st = entry(j);
             const int key0 = st * 32;
@@ -1186,7 +1190,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             if (!late && need) first_product_and_weights();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // B_j
-            if (j + 2 < ns) stage_dma(entry(j + 2), buf == 0 ? 2 : buf - 1);
+            // entry j + NBUF - 1 goes into the buffer entry j - 1 has left (every wave is past it: it passed B_j)
+            if (j + F16S_NBUF - 1 < ns) stage_dma(entry(j + F16S_NBUF - 1), buf == 0 ? F16S_NBUF - 1 : buf - 1);
             if (late && need) first_product_and_weights();
 
             if (live) {
@@ -1478,13 +1483,13 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
-    ms_iterate_d128_f16s_kernel<true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+    ms_iterate_d128_f16s_kernel<true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
         X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;

@@ -130,6 +130,9 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
  * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.03 rad). Clouds whose rows
  * are not unit vectors run the exact dense fp32 kernel. N <= 16 384. */
 int sed_ms_iterate_bounds_f16_refs(int N);
+/* 1 (default): block-sparse kernel on the four-plane stage images of the dense kernels (37 KiB per 32-key stage, 3 LDS
+ * buffers); 0: row-major-only stage images (17 KiB per stage, transpose reads, 6 buffers; measured 8 % slower). */
+int sed_ms_set_f16_sparse_config(int cfg);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
 int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   float skip_below, const float* tile_ref, const float* tile_cosalpha, float margin,

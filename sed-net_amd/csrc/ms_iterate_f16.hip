@@ -891,6 +891,411 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The software-pipelined kernel on ROW-MAJOR-ONLY stage images (end of round 2): the second product's A operand -- 8 keys of
+// one feature per lane -- comes from the same [key][feature] planes the first product reads, through gfx950's transpose read
+// (ds_read_b64_tr_b16), so the image drops its two transposed planes: 17 KiB per 32-key stage instead of 37 (17 LDS-DMA pieces
+// per block instead of 37, half the L2 / Infinity Cache traffic and half the LDS writes). Features are in natural order;
+// the O^T accumulator -> Q operand hand-off costs one half-wave exchange per row and iteration instead of being free.
+struct StageLayoutN {
+    static constexpr int XROW = 272, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, STAGE = 2 * XPLANE;   // 17408 B
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");
+};
+__host__ __device__ constexpr int sigma_row(int m) { return 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1); }
+
+// X [B, N, 128] fp32 -> row-major stage images [B, nst, 17408] (h plane | l plane, rows = keys in natural order, 272 B apart)
+__global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                         uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
+                                                         int nst) {
+    using L = StageLayoutN;
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
+    float n2max = 0.f;
+    for (int e = tid; e < 32 * 32; e += 256) {              // one float4 of one key row per step
+        const int kk = e >> 5, d0 = (e & 31) * 4;
+        const int key = stage * 32 + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * 128 + d0);
+        float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+        n2max = fmaxf(n2max, n2);
+        typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = v[u] * SCALE_X;
+            const h16 h = (h16)sc;
+            hh[u] = h;
+            ll[u] = (h16)(sc - (float)h);
+        }
+        *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
+        *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+    }
+    if (tid < 64) {                                          // the 16 pad bytes of every row (never read as data)
+        const int kk = tid & 31, pl = tid >> 5;
+        *(uint4*)(dst + pl * L::XPLANE + kk * L::XROW + 256) = make_uint4(0, 0, 0, 0);
+    }
+    const float b = bw[cloud];
+    if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
+}
+
+template <bool CHUNKED = false>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr) {
+    using L = StageLayoutN;
+    constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int RD = F16Q_RING_DISTANCE;                // the operand ring runs RD steps ahead
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
+    const int nst = (N + 31) >> 5;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+    // Q operand of k-step ks: features 16 ks + 8 hi + i in natural order (the stage images are row-major, unpermuted)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 16 * ks + 8 * hi + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+        }
+        split_q(ks, v);
+    }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 2 w, 2 w + 1 (immediate offset), wave 0 also piece 16
+    static_assert(NPIECE == 17, "piece distribution below is written for 17 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 2048 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 2048);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * 1024 + lane16),
+                                             (__attribute__((address_space(3))) void*)(dst + 16 * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once
+    int st_cur = s0, st_dma = s0;
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(s0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);
+    if (total > 2) stage_dma(st_dma, 2);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    h16x8 fa[4], fb[4];
+    // Per-lane LDS offsets of the operand reads (recomputed per block from a lane id the compiler cannot hoist: invariants
+    // that live across the register-hungry row update end up in scratch, and a reload's vmcnt wait in the hot loop also waits
+    // for the stage copy in flight).
+    //   first product: accumulator row m reads image row sigma(m), sigma(4 a + b) = 8 (a >> 1) + 2 b + (a & 1) -- a
+    //     permutation inside each group of 8 rows, conflict-free for ds_read_b128 like the identity, chosen so that
+    //   second product: the four keys of one transpose read (accumulator rows rho .. rho + 3) sit in image rows two apart
+    //     (8 banks): ds_read_b64_tr_b16 -- every lane passes the address of 4 consecutive features of one key, a 16-lane
+    //     group gets back the 4 keys x 16 features block transposed: lane = feature, 4 keys -- is then conflict-free on the
+    //     SAME row-major planes the first product reads. No transposed planes in the image: 17 KiB per stage instead of 37.
+    int xoff, toff;
+    auto refresh_offsets = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const int m = l & 31, h = l >> 5;
+        const int sig = 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1);
+        xoff = sig * XROW + h * 16;
+        const int i16 = l & 15;
+        toff = (2 * (i16 >> 2) + h) * XROW + 32 * ((l >> 4) & 1) + 8 * (i16 & 3);
+    };
+    refresh_offsets();
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {       // keys 16 j + {4 hi .. + 3, 8 + 4 hi .. + 3} of feature 32 c + li
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 8) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+    // first product of a block outside the pipeline (first block of the launch and of every sweep: Q has just changed),
+    // operands read directly; same MFMA order as the pipelined form -> same bits
+    auto plain_first_product = [&](const uint8_t* base) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+            s = mfma16(l, qh[t], s);
+            s = mfma16(a, ql[t], s);
+            s = mfma16(a, qh[t], s);
+        }
+        return s;
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % 3
+    i32x4 phv[2], plv[2];                                 // weights of the current block: two accumulator rows (fp16 pair) per dword
+    f32x16 s_cur;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+    if (total > 0) s_cur = plain_first_product(lds);
+    if (total > 1) {
+#pragma unroll
+        for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
+    }
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const uint8_t* n2base = lds + (nbuf == 2 ? 0 : nbuf + 1) * STAGE;
+        const int key0 = st_cur * 32;
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
+        const bool has_next = n + 1 < total && !sweep_end;
+        const bool tail = key0 + 32 > N;
+        refresh_offsets();
+
+        // weights of block n from s_cur, two accumulator rows at a time; TAIL: the cloud's last, partly filled stage
+        auto weights2 = [&](int t, auto tail_c) {
+            float p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * t + u;
+                p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
+                if (decltype(tail_c)::value && key0 + sigma_row(mfma_row(r, hi)) >= N) p[u] = 0.f;
+                rsum += p[u];
+            }
+            const h16x2 h = {(h16)p[0], (h16)p[1]};
+            const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+            phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+        };
+
+        // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
+        // (Measured on gfx950, tools/micro/mfma_valu_overlap.hip: VALU work of ANOTHER wave of the SIMD does not run under
+        // a wave's MFMAs -- 94 % of the serial time -- while independent VALU instructions interleaved into the SAME wave's
+        // MFMA stream do; the earlier schedules, staggered or not, ran matrix and vector phases back to back.)
+        f32x16 s_next;
+        auto phase1 = [&](auto tail_c) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_next = mfma16(fb[0], qh[0], z);
+                } else {
+                    s_next = mfma16(fb[t & 3], qh[t], s_next);
+                }
+                weights2(t, tail_c);
+                s_next = mfma16(fa[t & 3], ql[t], s_next);
+                s_next = mfma16(fa[t & 3], qh[t], s_next);
+                if (t + RD < 8) ring_load(t + RD, nbase);
+                else ring_load(t + RD, base);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_next) {
+            if (tail) phase1(std::true_type{});
+            else phase1(std::false_type{});
+        } else {                                          // last block of a sweep / of the launch: nothing to overlap with
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (tail) weights2(t, std::true_type{});
+                else weights2(t, std::false_type{});
+                if (t + RD >= 8) ring_load(t + RD, base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- phase 2: second product of block n. After step 13 nobody reads buffer n any more and everybody's pieces of
+        // block n + 2 (issued a block ago) have landed: barrier, then block n + 3 -> buffer n, and the ring moves on to
+        // block n + 2's first-product operands.
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
+            const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+            o[c] = mfma16(fb[t & 3], phj, o[c]);
+            o[c] = mfma16(fa[t & 3], plj, o[c]);
+            o[c] = mfma16(fa[t & 3], phj, o[c]);
+            if (t + RD < 16) ring_load(t + RD, base);
+            else if (n + 2 < total) ring_load(t + RD - 16, n2base);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 15 - RD) {                            // the last step that loads from this block's buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (n + 3 < total) stage_dma(st_dma, buf);
+                advance(st_dma, fwd_dma);
+            }
+        }
+
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (!sweep_end) {
+            s_cur = s_next;
+            continue;
+        }
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        // current Q in the accumulator layout (inverse of the hand-off below)
+        float qacc[4][16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;           // g = 0
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;   // g = 1
+                    const float keep = hi ? e1 : e0, send = hi ? e0 : e1;
+                    const float recv = __shfl_xor(send, 32, 64);
+                    // own half g = hi holds register 4 (2 j + hi) + u; the partner's element is register 4 (2 j + 1 - hi) + u
+                    qacc[c][8 * j + u] = hi ? recv : keep;
+                    qacc[c][8 * j + 4 + u] = hi ? keep : recv;
+                }
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = qacc[c][r];
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (n == total - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm, o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+            // accumulator (feature 32 c + (r & 3) + 8 (r >> 2) + 4 hi) -> Q operand (feature 16 ks + 8 hi + i): element
+            // i = 4 g + u of k-step 2 c + j is register 4 (2 j + hi) + u of lane half g -- own half for g = hi, the partner
+            // lane's otherwise (one exchange per row and iteration)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = (o[c][8 * j + u] / nrm) * SCALE_X, bq = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                        const float keep = hi ? bq : a, send = hi ? a : bq;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        v[u] = hi ? recv : keep;
+                        v[4 + u] = hi ? keep : recv;
+                    }
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+            s_cur = plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
+        }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Block-sparse schedule on the pipelined split-fp16 kernel (round 2; the fp32 version is ms_sparse.hip).
 // Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure, together with two unit reference
 // vectors per tile (normalised means of two groups of its rows) and cos(alpha) of each, alpha = the widest angle between
@@ -1297,6 +1702,420 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The block-sparse kernel on row-major-only stage images (ms_iterate_d128_f16r_kernel's layout and transpose reads): half the
+// bytes per listed stage -- its counters show 132 GB per launch fetched from beyond L2 for 177 GB of stage copies -- and, at
+// 17 KiB per stage, six stage buffers instead of three. An experiment that answered its question: it is 8 % SLOWER than the
+// four-plane kernel (twice the LDS read instructions in the second product), so copy traffic is not what bounds the sparse
+// schedule. Kept selectable (sed_ms_set_f16_sparse_config(0)) with its tests; not the default.
+#ifndef F16T_NBUF
+#define F16T_NBUF 6
+#endif
+#ifndef F16T_REFGROUP
+#define F16T_REFGROUP 11                              // 11 x 9 KiB reference head planes <= 6 x 17 KiB of stage buffers
+#endif
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
+    unsigned long long* __restrict__ stats) {
+    using L = StageLayoutN;
+    constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
+    constexpr int MAXW = F16S_MAXW, NBUF = F16T_NBUF, REFGROUP = F16T_REFGROUP;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE] (and REFGROUP reference head planes)
+    __shared__ unsigned long long wmask[8][MAXW];
+    __shared__ int slist[512];
+    __shared__ int wcount[8];
+    __shared__ float wmoved[8];
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + 31) >> 5;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            // slot rho = image * 32 + accumulator row m; that row reads image row sigma(m): tile 32 (image / 2) + sigma(m)
+            const int srow = sigma_row(rho & 31);
+            const int t = (rho >> 6) * 32 + srow;        // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + (rho & ~31) + srow], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                      // Q operand of k-step ks: features 16 ks + 8 hi + i, natural order
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 tq = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 16 * ks + 8 * hi + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * g + u] = tq[u] * SCALE_X;
+        }
+        split_q(ks, v);
+    }
+
+    static_assert(NPIECE == 17, "piece distribution below is written for 17 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 2048 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 2048);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * 1024 + lane16),
+                                             (__attribute__((address_space(3))) void*)(dst + 16 * 1024), 16, 0, 0);
+    };
+
+    h16x8 fa[4], fb[4];
+    // row sigma(li) of the image for the first product, transpose reads for the second: see ms_iterate_d128_f16r_kernel
+    const int xoff = sigma_row(li) * XROW + hi * 16;
+    const int toff = (2 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 8) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    h16x8 ph[2], pl[2];
+    unsigned long long n_listed = 0, n_first = 0, n_second = 0, n_remake = 0;      // per-wave counts (statistics only)
+
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
+    // The rows at mask time are parked in the output rows (row-private; overwritten by the result at the end).
+    int ns = 0;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous iteration's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) mx = fmaxf(mx, wmoved[w]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+        if (qrow < N) {                                  // remember where the masks were made: the row's slot of the output
+            float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = ((float)qh[ks][4 * g + u] + (float)ql[ks][4 * g + u]) * UNSCALE_Q;
+                    *(f32x4*)(keep + 16 * ks + 8 * hi + 4 * g) = v;
+                }
+        }
+        // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
+        for (int g0 = 0; g0 < nrs; g0 += REFGROUP) {
+            const int ng = min(REFGROUP, nrs - g0);
+            if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
+            for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
+                const int im = pc / 9, piece = pc - 9 * im;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                    (__attribute__((address_space(3))) void*)(lds + im * F16S_REFBYTES + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int im = 0; im < ng; ++im) {
+                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff;
+                f32x16 sr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                unsigned word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * g + u] > th[u]);
+                        word |= ((unsigned)bal != 0u ? 1u : 0u) << sigma_row(8 * g + u);              // tile of lane half 0's row
+                        word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << sigma_row(8 * g + u + 4);  // ... of lane half 1's
+                    }
+                }
+                if (lane == 0) {                                  // a tile is needed if either of its references is near
+                    unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                    *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                }
+            }
+        }
+        if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
+        __syncthreads();
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
+        {
+            bool need = false;
+            if (tid < nst) {
+                const int w = tid >> 6, sh = tid & 63;
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) any |= wmask[v][w];
+                need = (any >> sh) & 1ull;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = 0;
+            ns = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int cnt = wcount[w];
+                if (w < wave) base += cnt;
+                ns += cnt;
+            }
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tid;
+        }
+        __syncthreads();
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        ++n_remake;
+        }   // remake
+        n_listed += ns;
+
+        // ---- (4) the pipeline over the list
+        const bool fwd = (it & 1) == 0;
+        auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
+        if (ns > 0) stage_dma(entry(0), 0);
+        if (ns > 1) stage_dma(entry(1), 1);
+#pragma unroll
+        for (int pj = 2; pj < NBUF - 1; ++pj)
+            if (ns > pj) stage_dma(entry(pj), pj);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ns > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) ring_load(t, lds);
+        }
+        int buf = 0;
+        for (int j = 0; j < ns; ++j) {
+            const uint8_t* base = lds + buf * STAGE;
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+            const uint8_t* nbase = lds + nbuf * STAGE;
+            const int st = entry(j);
+            const int key0 = st * 32;
+            const bool need =
+                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            bool live = false;
+
+            auto first_product_and_weights = [&]() {
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s = mfma16(fb[t & 3], qh[t], s);
+                    s = mfma16(fa[t & 3], ql[t], s);
+                    s = mfma16(fa[t & 3], qh[t], s);
+                    ring_load(t + 2, base);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + sigma_row(mfma_row(r, hi)) >= N) p[r] = 0.f;
+                }
+                float pmax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    rsum += p[r];
+                    pmax = fmaxf(pmax, p[r]);
+                    const h16 h = (h16)p[r];
+                    ph[r >> 3][r & 7] = h;
+                    pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                }
+                // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
+                live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
+                ++n_first;
+            };
+
+            if (need) first_product_and_weights();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // B_j
+            // entry j + NBUF - 1 goes into the buffer entry j - 1 has left (every wave is past it: it passed B_j)
+            if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
+
+            if (live) {
+                ++n_second;
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    const int c = (t - 8) >> 1, jj = (t - 8) & 1;
+                    o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if (t + 2 < 16) ring_load(t + 2, base);
+                    else if (j + 1 < ns) ring_load(t + 2 - 16, nbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (j + 1 < ns) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) ring_load(t, nbase);
+            }
+            buf = nbuf;
+        }
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float qacc[4][16];                               // current Q in the accumulator layout (see ms_iterate_d128_f16r_kernel)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;
+                    const float keepv = hi ? e1 : e0, send = hi ? e0 : e1;
+                    const float recv = __shfl_xor(send, 32, 64);
+                    qacc[c][8 * j + u] = hi ? recv : keepv;
+                    qacc[c][8 * j + 4 + u] = hi ? keepv : recv;
+                }
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = qacc[c][r];
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
+            float ch2 = 0.f;
+            if (qrow < N) {
+                const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 k = *(const f32x4*)(keep + 32 * c + 8 * g + 4 * hi);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dlt = o[c][4 * g + u] * inv - k[u];
+                            ch2 = fmaf(dlt, dlt, ch2);
+                        }
+                    }
+            }
+            ch2 += xor32(ch2);
+            float wm = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            if (lane == 0) wmoved[wave] = wm;            // read after the barrier that opens the next iteration
+        }
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = (o[c][8 * j + u] / nrm) * SCALE_X, bq = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                        const float keepv = hi ? bq : a, send = hi ? a : bq;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        v[u] = hi ? recv : keepv;
+                        v[4 + u] = hi ? keepv : recv;
+                    }
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+    if (stats && lane == 0) {
+        // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
+        // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
+        if (wave == 0) atomicAdd(stats + 0, n_listed);
+        atomicAdd(stats + 1, n_first);
+        atomicAdd(stats + 2, n_second);
+        atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
+        if (wave == 0) atomicAdd(stats + 4, n_remake);
+    }
+}
+
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
@@ -1308,7 +2127,7 @@ int g_ms_f16_cfg = 0;
 
 static size_t f16_blob_bytes(int B, int N, int cfg) {
     const size_t kt = cfg == 2 ? 64 : 32;
-    const size_t stage = cfg == 2 ? StageLayout<64>::STAGE : StageLayout<32>::STAGE;
+    const size_t stage = cfg == 2 ? StageLayout<64>::STAGE : cfg == 5 ? StageLayoutN::STAGE : StageLayout<32>::STAGE;
     return (size_t)B * ((N + kt - 1) / kt) * stage;
 }
 
@@ -1381,6 +2200,24 @@ static int f16q_launch(int B, int N, int iters, const float* bw, const float* X,
     return SED_OK;
 }
 
+static int f16r_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       hipStream_t stream) {
+    using L = StageLayoutN;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16r_kernel<false><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N,
+                                                                                                 iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
 // key-chunked split-fp16 schedule: chunk count from N only (results do not depend on how many clouds share a launch):
 // as many chunks as fill the 256 CUs with ONE cloud's workgroups, at least 8 stages per chunk; 0 = not worth it
 int ms_f16_chunks(int N) {
@@ -1448,6 +2285,7 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 0) return f16q_launch(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 5) return f16r_launch(B, N, iters, bw, X, newX, blob, flags, stream);
     return g_ms_f16_cfg == 4 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
                              : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
 }
@@ -1458,26 +2296,49 @@ static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 
 // stage images of the sorted rows | flags | stage images of the tile references | scratch flags
 size_t ms_f16_sparse_workspace_bytes(int B, int N) {
     const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
-    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 2 * f16_flag_bytes(B);
+    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 2 * f16_flag_bytes(B);      // sized for either image format
 }
 
 // Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
 // row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated).
+// g_ms_f16_sparse_cfg: 1 = ms_iterate_d128_f16s_kernel (four-plane images, 3 buffers; default), 0 = ms_iterate_d128_f16t_kernel
+// (row-major-only stage images, transpose reads, 6 buffers: half the copy traffic, and 8 % slower -- 54.6 vs 50.5 ms on the
+// 64-cloud clustered benchmark: the copies are not what holds the sparse kernel)
+int g_ms_f16_sparse_cfg = 1;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, hipStream_t stream) {
-    using L = StageLayout<32>;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
+    const int cfg = g_ms_f16_sparse_cfg == 0 ? 5 : 0;                  // image format of f16_blob_bytes
     uint8_t* blob = (uint8_t*)workspace;
-    int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, cfg));
     uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
-    int* flags2 = (int*)(refblob + f16_blob_bytes(B, nrs * 32, 0));
+    int* flags2 = (int*)(refblob + f16_blob_bytes(B, nrs * 32, cfg));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    if (g_ms_f16_sparse_cfg == 0) {
+        using L = StageLayoutN;
+        constexpr int smem = F16T_NBUF * L::STAGE > F16T_REFGROUP * F16S_REFBYTES ? F16T_NBUF * L::STAGE
+                                                                                 : F16T_REFGROUP * F16S_REFBYTES;
+        static bool attr = false;
+        if (!attr) {
+            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+        ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+        ms_iterate_d128_f16t_kernel<true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
+    using L = StageLayout<32>;
     static bool attr = false;
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
@@ -1495,8 +2356,14 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     return SED_OK;
 }
 
+extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
+    if (cfg < 0 || cfg > 1) return SED_EINVAL;
+    g_ms_f16_sparse_cfg = cfg;
+    return SED_OK;
+}
+
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 4) return SED_EINVAL;
+    if (cfg < 0 || cfg > 5) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sed_ms_iterate_sparse_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P]),
     "sed_ms_iterate_bounds_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, P, P, P, c_int, c_float, P]),
     "sed_fps_pivots_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "sed_ms_set_f16_sparse_config": (c_int, [c_int]),
     "sed_ms_iterate_bounds_f16_refs": (c_int, [c_int]),
     "sed_ms_iterate_bounds_f16_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_iterate_bounds_f16_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, c_size_t, P,

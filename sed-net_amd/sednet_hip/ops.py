@@ -380,7 +380,7 @@ def ms_set_variant(variant):
     the first, unpipelined version with 64-key / 32-key stages)."""
     global _MS_VARIANT
     _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
-    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4}.get(variant, 0)), "ms_set_f16_config")
+    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5}.get(variant, 0)), "ms_set_f16_config")
     check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5}.get(variant, 4)),
           "ms_set_variant")
 

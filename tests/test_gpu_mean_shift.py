@@ -49,7 +49,7 @@ def variant(request):
     ops.MS_SPARSE = "auto"
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c", "sparse"],
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "sparse"],
                          indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
@@ -327,6 +327,36 @@ def test_block_sparse_split_fp16_edges(T, N):
         d1 = ops._ms_iterate_dense(Xb, bw[:1], 1).cpu().numpy()
         np.testing.assert_allclose(ops.ms_iterate_sparse(Xb, bw[:1], 1).cpu().numpy(), d1, atol=2e-5)
         np.testing.assert_array_equal(ops.ms_iterate(Xb, bw[:1], 1).cpu().numpy(), d1)
+
+
+def test_row_major_only_stage_images(T):
+    """The experimental kernels on 17 KiB row-major-only stage images (second-product operands by ds_read_b64_tr_b16, no
+    transposed planes): dense ("f16r") and block-sparse (sed_ms_set_f16_sparse_config(0)) against the default kernels --
+    the same rows up to the summation order inside a 32-key stage (keys are permuted within a stage), the same visit counts."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import check, lib
+    Xs = np.stack([synth.clustered_embedding(N=5003, d=128, n_clusters=8 + 2 * c, sigma=0.01, seed=400 + c)[0] for c in range(3)])
+    X = dev(T, Xs)
+    bw = ops.ms_bandwidth(X, 75, 0.003)
+    try:
+        ops.ms_set_variant("f16")
+        ref = ops._ms_iterate_dense(X, bw, 20).cpu().numpy()
+        ops.ms_set_variant("f16r")
+        got = ops._ms_iterate_dense(X, bw, 20).cpu().numpy()
+    finally:
+        ops.ms_set_variant("auto")
+    np.testing.assert_allclose(got, ref, atol=3e-6)
+    st = [T.zeros(5, dtype=T.int64, device="cuda") for _ in range(2)]
+    sp = ops.ms_iterate_sparse(X, bw, 20, stats=st[0]).cpu().numpy()
+    try:
+        check(lib.sed_ms_set_f16_sparse_config(0), "cfg")
+        sp_n = ops.ms_iterate_sparse(X, bw, 20, stats=st[1]).cpu().numpy()
+    finally:
+        check(lib.sed_ms_set_f16_sparse_config(1), "cfg")
+    np.testing.assert_allclose(sp_n, sp, atol=3e-6)
+    np.testing.assert_allclose(sp_n, ref, atol=3e-6)
+    a, b_ = st[0].cpu().numpy(), st[1].cpu().numpy()
+    assert a[3] == b_[3] and abs(int(a[0]) - int(b_[0])) <= 0.01 * a[0]          # (a knife-edge threshold may flip a tile)
 
 
 def test_nan_cloud_does_not_derail_the_sparse_path(T):

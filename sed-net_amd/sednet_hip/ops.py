@@ -51,6 +51,17 @@ def _pair_ws(nb, N, device):
 
 FUSED_KNN = True          # streaming two-sweep kNN (knn_fused.hip); False forces the materialised exact path
 FUSED_STATS = {"fused": 0, "fallback": 0}
+# None: every streaming kNN call reads its overflow flag right away (one blocking 4-byte copy per call). A list: the flags are
+# appended instead and the CALLER checks them once (deferred_knn_overflow) and repeats its work with FUSED_KNN = False if one
+# is set -- the batched pipeline does this per step (5 syncs -> 1), and it is what lets the forwards be captured in a HIP graph.
+DEFERRED_KNN_FLAGS = None
+
+
+def deferred_knn_overflow(flags):
+    """True if any of the collected overflow flags is set (one D->H copy)."""
+    if not flags:
+        return False
+    return bool(torch.stack([f.reshape(()) for f in flags]).any().item())
 
 
 def _fused_ws(B, N, device):
@@ -68,6 +79,9 @@ def knn_features(X, k, C=None):
         ws, nbytes = _fused_ws(B, N, X.device)
         flag = torch.empty((1,), dtype=torch.int32, device=X.device)
         check(lib.sed_knn_fused_f32(B, N, D, C, k, ptr(X), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()), "knn_fused")
+        if DEFERRED_KNN_FLAGS is not None:
+            DEFERRED_KNN_FLAGS.append(flag)
+            return idx
         if int(flag.item()) == 0:          # one tiny D->H copy; overflow only with masses of duplicate points
             FUSED_STATS["fused"] += 1
             return idx
@@ -116,6 +130,9 @@ def knn_points_normals(x6, k, W=1.0):
         flag = torch.empty((1,), dtype=torch.int32, device=x6.device)
         check(lib.sed_knn_pn_fused_f32(B, N, k, float(W), ptr(x6), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()),
               "knn_pn_fused")
+        if DEFERRED_KNN_FLAGS is not None:
+            DEFERRED_KNN_FLAGS.append(flag)
+            return idx
         if int(flag.item()) == 0:
             FUSED_STATS["fused"] += 1
             return idx

@@ -8,8 +8,8 @@ caller is Fitting_patches_and_edges/residual_utils.py:86-331:
     per segment: type vote (stats.mode) -> LSQ fit -> closed-form residual     residual_utils.py:259, :300-331
 
 B clouds go through every stage in one launch each. Host syncs per step, all of them copies of a few bytes per cloud: the
-overflow flags of the five streaming kNN calls (ops.knn_features / knn_points_normals: a raised flag re-runs the exact
-path), and per guard pass the bandwidth kernel's per-cloud overflow flags, the density probe that picks the mean-shift
+overflow flags of the five streaming kNN calls, read together once after both forwards (a raised flag repeats the forwards
+on the exact path), and per guard pass the bandwidth kernel's per-cloud overflow flags, the density probe that picks the mean-shift
 schedule (ops.ms_near_fraction) and the cluster counts the guard loop branches on (the reference's :31; it syncs at least
 three times per CLOUD and pass, plus a numpy round trip).
 """
@@ -46,6 +46,42 @@ class SegmentationPipeline:
         self.quantile, self.iterations, self.S, self.fit = quantile, iterations, max_segments, fit
         self.ms, self.dist = MeanShift(), dist
 
+    def _forwards(self, x6, ev=None):
+        """both models on x6 -> (log_prob, t_model, emb, edges, X, overflow flags)"""
+        flags = []
+        prev, ops.DEFERRED_KNN_FLAGS = ops.DEFERRED_KNN_FLAGS, flags
+        try:
+            # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
+            e0, e1 = self.model_type.encoder, self.model_inst.encoder
+            idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+            if ev is not None:
+                ev.mark("input_graph")
+            _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
+            t_model = ops.row_argmax(log_prob, log_prob.shape[2])
+            if ev is not None:
+                ev.mark("type_model")
+            emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
+            X = ops.row_normalize(emb, emb.shape[2])
+        finally:
+            ops.DEFERRED_KNN_FLAGS = prev
+        return log_prob, t_model, emb, edges, X, flags
+
+    def _forwards_checked(self, x6, ev=None):
+        """the streaming kNN kernels' overflow flags are read ONCE for the whole step; a raised flag (masses of duplicate
+        points) repeats the forwards on the exact materialised path. (Replaying the forwards from a HIP graph was tried for
+        the one-cloud-per-call pattern and changes nothing -- 5.85 vs 5.83 ms: at B = 1 they are bound by the run time of
+        single workgroups sweeping all key tiles, not by launches.)"""
+        log_prob, t_model, emb, edges, X, flags = self._forwards(x6, ev)
+        if not ops.deferred_knn_overflow(flags):
+            ops.FUSED_STATS["fused"] += len(flags)
+            return log_prob, t_model, emb, edges, X
+        ops.FUSED_STATS["fallback"] += len(flags)
+        prev, ops.FUSED_KNN = ops.FUSED_KNN, False
+        try:
+            return self._forwards(x6, ev)[:5]
+        finally:
+            ops.FUSED_KNN = prev
+
     @torch.no_grad()
     def __call__(self, x6, embedding=None, types=None):
         """x6 [B,6,N] (xyz + unit normals, channel-major like SEDNet.forward) -> dict of device tensors.
@@ -54,15 +90,7 @@ class SegmentationPipeline:
         weights cannot produce; with real checkpoints leave them None)."""
         ev = _StageTimer(self.stage_times)
         x6 = x6.float().contiguous()
-        # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
-        e0, e1 = self.model_type.encoder, self.model_inst.encoder
-        idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
-        ev.mark("input_graph")
-        _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
-        t_model = ops.row_argmax(log_prob, log_prob.shape[2])
-        ev.mark("type_model")
-        emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
-        X = ops.row_normalize(emb, emb.shape[2])
+        log_prob, t_model, emb, edges, X = self._forwards_checked(x6, ev)
         if embedding is not None:
             X = ops.row_normalize(embedding.float().contiguous(), embedding.shape[2])
         types = t_model if types is None else types.int().contiguous()

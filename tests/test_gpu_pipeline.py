@@ -140,3 +140,28 @@ def test_evaluation_caller_matches_reference(T, golden, tag):
     ref_t = G("train_loss")                                       # [Loss, geometric, s_iou, p_iou]
     np.testing.assert_allclose([float(loss_t[0]), float(loss_t[1])], ref_t[:2], rtol=0.2, atol=5e-4)
     np.testing.assert_allclose([loss_t[3], loss_t[4]], ref_t[2:], atol=1e-7)
+
+
+def test_deferred_knn_overflow_flags(T):
+    """The streaming kNN kernels' overflow flags are read once per pipeline step; a raised flag (many identical points)
+    repeats the forwards on the exact path -- the same labels and types as forcing the exact path from the start."""
+    from sednet_hip import ops, synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    import bench
+    m_type, m_inst = bench.build_models(20, T.device("cuda"))
+    x = T.from_numpy(synth.batch_clouds(2, 4096, seed0=77)[0]).cuda()
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=10)
+    before = dict(ops.FUSED_STATS)
+    pipe(x)
+    assert ops.FUSED_STATS["fused"] >= before["fused"] + 5 and ops.FUSED_STATS["fallback"] == before["fallback"]
+    xd = x[0:1].clone()
+    xd[0, :, 100:400] = xd[0, :, 100:101]                    # 300 identical points
+    before = dict(ops.FUSED_STATS)
+    a = pipe(xd)
+    assert ops.FUSED_STATS["fallback"] >= before["fallback"] + 5
+    try:
+        ops.FUSED_KNN = False
+        c = pipe(xd)
+    finally:
+        ops.FUSED_KNN = True
+    assert T.equal(a["labels"], c["labels"]) and T.equal(a["types"], c["types"])

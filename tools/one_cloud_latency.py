@@ -8,7 +8,7 @@ import numpy as np, torch
 import bench
 from sednet_hip import ops, synth
 from sednet_hip.pipeline import SegmentationPipeline
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 x_np, l_np, t_np = synth.batch_clouds(n, 10000, seed0=1234)
 x = torch.from_numpy(x_np).cuda()
 m_type, m_inst = bench.build_models(20, torch.device("cuda"))

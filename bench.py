@@ -19,9 +19,10 @@ line says "scaling": "strong"; at N = 1 that is 8 x 64 clouds per step.
 The JSON line also carries
   roofline     : the dominant kernel (mean-shift iterations: 94 % of the path's algorithmic flops), timed live with events
                  on the launch stream inside the timed region. `achieved` = ALGORITHMIC flops (4 N^2 D iters per cloud,
-                 SURVEY.md section 8(d)) / launch time. The kernel evaluates each of the two fp32 products as 3 fp16 MFMAs
-                 (split-fp16 emulation, fp32-equivalent error), so its matrix-pipe roof for algorithmic flops is the dense
-                 fp16 MFMA peak / 3 (`peak`); the fraction of the fp32-MFMA peak the exact kernel was bound by is given too.
+                 SURVEY.md section 8(d)) / launch time. The kernel evaluates the first fp32 product as 3 fp16 MFMAs
+                 (split-fp16 emulation on exact (h, l) digits) and the second as 2 (fp16 heads of the weights x (h, l) digits
+                 of X), so its matrix-pipe roof for algorithmic flops is the dense fp16 MFMA peak / 2.5 (`peak`); the
+                 fraction of the fp32-MFMA peak the exact kernel was bound by is given too.
   hbm_frac     : algorithmic HBM bytes of the whole path / time / 8 TB/s (north_star asks for it; structurally low: the
                  dominant stage is a dense contraction whose operands live in LDS / L2).
   realistic    : the same step with the embedding and the per-point types replaced -- AFTER both forwards ran -- by ones
@@ -46,6 +47,7 @@ for p in (ROOT, os.path.join(ROOT, "sed-net_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+MFMA_PER_PRODUCT = 2.5                 # split-fp16 mean-shift kernel: 3 fp16 MFMAs for S = Q X^T, 2 for O = P X (fp16-head weights)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 / bf16 MFMA
 HBM_PEAK_TBS = 8.0
@@ -227,7 +229,7 @@ def main():
     avg_clouds = float(np.mean([m["B"] for _, m in it]))
     ach = flops_per_cloud * avg_clouds / (avg_ms * 1e-3) / 1e12
     split = all(m.get("schedule") == "split-fp16" for _, m in it)
-    peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+    peak = F16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT if split else FP32_MFMA_PEAK_TFLOPS
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_ms_iterate.json")
     if os.path.exists(pmc):
@@ -245,9 +247,11 @@ def main():
             "value": round(cps, 3), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32 (mean-shift products: split-fp16 MFMA emulation, 3 fp16 MFMAs per fp32 product on exact (h,l) "
-                     "splits, fp32 accumulate, fp32-equivalent error; selection dot products: the same split; head GEMMs: 3-way bf16 "
-                     "splits, 6 bf16 MFMAs per product; EdgeConv: fp32-input MFMA)" if split else "f32",
+            "dtype": "f32 (mean-shift products on the fp16 matrix pipe, fp32 accumulate: S = Q X^T as 3 fp16 MFMAs on exact "
+                     "(h,l) splits, fp32-equivalent error; O = P X as 2 fp16 MFMAs: fp16 heads of the weights, consistently in "
+                     "numerator and row sum, x (h,l) splits of X -- rows within 1e-6 of the exact fp32 kernel, golden "
+                     "tolerances unchanged; selection dot products: 3-MFMA split; head GEMMs: 3-way bf16 splits, 6 bf16 "
+                     "MFMAs per product; EdgeConv: fp32-input MFMA)" if split else "f32",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: " if (B, N, args.k) == (64, 10000, 20) and not strong else
                                     (f"BASELINE configs[3]-style fixed job of {args.total_clouds} clouds: " if strong else "")) +
@@ -261,10 +265,11 @@ def main():
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 3),
                          "flops_per_launch": flops_per_cloud * avg_clouds,
-                         "note": ("achieved = algorithmic fp32 flops / launch time; the kernel executes 3 x as many fp16-MFMA "
-                                  "flops, peak = 2500 / 3 TFLOP/s of algorithmic flops") if split else None,
-                         "executed_f16_mfma_tflops": round(3 * ach, 1) if split else None,
-                         "frac_of_f16_mfma_peak": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
+                         "note": ("achieved = algorithmic fp32 flops / launch time; the kernel executes 2.5 x as many fp16-MFMA "
+                                  "flops (3 MFMAs per first, 2 per second product), peak = 2500 / 2.5 TFLOP/s of algorithmic "
+                                  "flops") if split else None,
+                         "executed_f16_mfma_tflops": round(MFMA_PER_PRODUCT * ach, 1) if split else None,
+                         "frac_of_f16_mfma_peak": round(MFMA_PER_PRODUCT * ach / F16_MFMA_PEAK_TFLOPS, 4) if split else None,
                          "x_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 3)},
             "hbm_frac": {"algorithmic_bytes_per_cloud": ALG_BYTES_PER_CLOUD(N),
                          "achieved_GBs": round(ALG_BYTES_PER_CLOUD(N) * cps / 1e9, 2), "peak_GBs": HBM_PEAK_TBS * 1e3 * world,

@@ -749,7 +749,8 @@ __global__ __launch_bounds__(256, 2) void ms_partial_d128_kernel(const float* __
 __global__ __launch_bounds__(256) void ms_combine_kernel(const float* __restrict__ partO,
                                                          const float* __restrict__ partS,
                                                          const float* __restrict__ Qin, float* __restrict__ Qout,
-                                                         size_t rows, int nchunk, int D) {
+                                                         size_t rows, int nchunk, int D, int N = 0,
+                                                         int* __restrict__ lowq = nullptr) {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int l = threadIdx.x & 63;
     if (row >= rows) return;
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(256) void ms_combine_kernel(const float* __restrict
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
     const float nrm = sqrtf(n2);
+    if (lowq != nullptr && nrm < 0.5f) lowq[row / (size_t)N] = 1;     // see ms_iterate_d128_f16q_kernel: weighted mean cancels
     if (act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) nq[e] = nq[e] / nrm;
@@ -830,7 +832,7 @@ int g_ms_variant = 0;      // 0 = choose by size, 1 = batched fp32, 2 = split-ke
 size_t ms_f16_chunked_workspace_bytes(int B, int N);
 int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
-                                                          hipStream_t),
+                                                          int, int*, hipStream_t),
                           hipStream_t stream);
 size_t ms_f16_workspace_bytes(int B, int N);
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
@@ -842,8 +844,8 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
                          float margin, unsigned long long* stats, hipStream_t stream);
 
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
-                             hipStream_t stream) {
-    ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, 128);
+                             int N, int* lowq, hipStream_t stream) {
+    ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, 128, N, lowq);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

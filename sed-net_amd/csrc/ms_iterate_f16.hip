@@ -572,7 +572,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 #ifndef F16Q_RING_DISTANCE
 #define F16Q_RING_DISTANCE 2
 #endif
-template <bool CHUNKED = false>
+// PL = false ("f16h", 5 MFMAs per block pair instead of 6): the weights enter the second product -- and the row sum, consistently --
+// as their fp16 heads only, O = sum_j fp16(2^14 p_j) (xh_j + xl_j) / sum_j fp16(2^14 p_j): an exactly evaluated weighted mean
+// under weights perturbed by <= 2^-12 relative, independently per key. The perturbation of a row is
+// sum_j p_j e_j (x_j - o) / sum_j p_j ~ 2^-12 / sqrt(3) * (spread of the keys under the kernel) / sqrt(#effective keys):
+// 1e-7 .. 9e-7 on the golden snapshots (tools/f16split_emulation.py) against their 2e-6 / 5e-6 / 1e-5 tolerances. The first
+// product keeps its three terms: an error there is amplified by 1 / b^2.
+template <bool CHUNKED = false, bool PL = true>
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
@@ -580,7 +586,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
                                                                       const int* __restrict__ flags, int N, int iters,
                                                                       const float* __restrict__ Qin = nullptr,
                                                                       float* __restrict__ partO = nullptr,
-                                                                      float* __restrict__ partS = nullptr) {
+                                                                      float* __restrict__ partS = nullptr,
+                                                                      int* __restrict__ lowq = nullptr) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int RD = F16Q_RING_DISTANCE;                // the operand ring runs RD steps ahead
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
     int bx;
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
     const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
     const int nst = (N + 31) >> 5;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
@@ -745,12 +753,16 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
                 const int r = 2 * t + u;
                 p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
                 if (decltype(tail_c)::value && key0 + mfma_row(r, hi) >= N) p[u] = 0.f;
-                rsum += p[u];
+                if (PL) rsum += p[u];
             }
             const h16x2 h = {(h16)p[0], (h16)p[1]};
-            const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
             phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
-            plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            if (PL) {
+                const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+                plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            } else {
+                rsum += (float)h[0] + (float)h[1];          // the row sum of the weights the product actually uses
+            }
         };
 
         // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
@@ -799,9 +811,11 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
         for (int t = 8; t < 16; ++t) {
             const int c = (t - 8) >> 1, j = (t - 8) & 1;
             const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
-            const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
             o[c] = mfma16(fb[t & 3], phj, o[c]);
-            o[c] = mfma16(fa[t & 3], plj, o[c]);
+            if (PL) {
+                const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+                o[c] = mfma16(fa[t & 3], plj, o[c]);
+            }
             o[c] = mfma16(fa[t & 3], phj, o[c]);
             if (t + RD < 16) ring_load(t + RD, base);
             else if (n + 2 < total) ring_load(t + RD - 16, n2base);
@@ -836,6 +850,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
             }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
+        // The weighted mean of a row nearly cancels (|o| < 1/2: unstructured rows under a bandwidth that spans the cloud): the
+        // normalisation would amplify the rounding of the fp16-head weights by 1 / |o|. Flag the cloud; the launcher re-runs
+        // flagged clouds with (h, l) weights behind this launch.
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
         if (n == total - 1) {
             if (qrow < N) {
                 float* out = newX + ((size_t)cloud * N + qrow) * 128;
@@ -1326,12 +1344,12 @@ constexpr int F16S_REFGROUP = 12;                 // reference images per LDS lo
 constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
 constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
 
-template <bool STAGGER>
+template <bool STAGGER, bool PL = true>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq = nullptr) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
@@ -1349,6 +1367,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     int bx;
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
     const float* Xc = X + (size_t)cloud * N * 128;
     const int nst = (N + 31) >> 5;
     const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
@@ -1581,11 +1600,15 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
                 float pmax = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    rsum += p[r];
                     pmax = fmaxf(pmax, p[r]);
                     const h16 h = (h16)p[r];
                     ph[r >> 3][r & 7] = h;
-                    pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    if (PL) {
+                        rsum += p[r];
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    } else {
+                        rsum += (float)h;
+                    }
                 }
                 // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
                 live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
@@ -1605,7 +1628,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
                 for (int t = 8; t < 16; ++t) {
                     const int c = (t - 8) >> 1, jj = (t - 8) & 1;
                     o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
-                    o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
                     o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
                     if (t + 3 < 16) ring_load(t + 3, base);
                     else if (j + 1 < ns) ring_load(t + 3 - 16, nbase);
@@ -1634,6 +1657,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;       // see ms_iterate_d128_f16q_kernel
         if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
             float ch2 = 0.f;
             if (qrow < N) {
@@ -2119,11 +2143,14 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
-// cfg 0: software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1; default);
+// cfg 0: software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1) with fp16-head weights
+// in the second product (5 MFMAs per block pair; default); 6: the same kernel with (h, l) weights (6 MFMAs);
 // 1: round-2 pipelined kernel, wave groups in phase; 4: the same, groups half a block out of phase (the default until the
 // software-pipelined kernel); 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave
 // workgroups per CU
 int g_ms_f16_cfg = 0;
+
+static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
 
 static size_t f16_blob_bytes(int B, int N, int cfg) {
     const size_t kt = cfg == 2 ? 64 : 32;
@@ -2131,8 +2158,9 @@ static size_t f16_blob_bytes(int B, int N, int cfg) {
     return (size_t)B * ((N + kt - 1) / kt) * stage;
 }
 
+// stage images | "rows not unit" flags | "weighted means cancel" flags (both per cloud, 256-byte blocks)
 size_t ms_f16_workspace_bytes(int B, int N) {
-    return f16_blob_bytes(B, N, g_ms_f16_cfg) + (((size_t)B * sizeof(int) + 255) / 256) * 256;
+    return f16_blob_bytes(B, N, g_ms_f16_cfg) + 2 * ((((size_t)B * sizeof(int) + 255) / 256) * 256);
 }
 
 template <int KT_, int NW>
@@ -2179,8 +2207,11 @@ static int f16p_launch(int B, int N, int iters, const float* bw, const float* X,
     return SED_OK;
 }
 
+// PL = false: heads-only weights, clouds whose weighted means cancel are flagged in `lowq` and done again with (h, l) weights
+// by a second launch whose workgroups return at once for every other cloud
+template <bool PL>
 static int f16q_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
-                       hipStream_t stream) {
+                       int* lowq, hipStream_t stream) {
     using L = StageLayout<32>;
     const int nst = (N + 31) / 32;
     static bool attr = false;
@@ -2188,14 +2219,20 @@ static int f16q_launch(int B, int N, int iters, const float* bw, const float* X,
         hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<32>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, PL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
-    ms_iterate_d128_f16q_kernel<false><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N,
-                                                                                                 iters);
+    ms_iterate_d128_f16q_kernel<false, PL><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, PL ? nullptr : lowq);
+    if (!PL)
+        ms_iterate_d128_f16q_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -2235,7 +2272,7 @@ size_t ms_f16_chunked_workspace_bytes(int B, int N) {
 // one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher
 int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
-                                                          hipStream_t),
+                                                          int, int*, hipStream_t),
                           hipStream_t stream) {
     using L = StageLayout<32>;
     const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
@@ -2243,8 +2280,9 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
     int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
     float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + ms_f16_workspace_bytes(B, N)) + 255) & ~(uintptr_t)255);
     float* partS = partO + (size_t)B * N * S * 128;
+    int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
     if (e != hipSuccess) return (int)e;
     static bool attr = false;
     if (!attr) {
@@ -2253,7 +2291,13 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<true, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
         attr = true;
@@ -2261,15 +2305,22 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
-        if (g_ms_f16_cfg == 0)
-            ms_iterate_d128_f16q_kernel<true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+        if (g_ms_f16_cfg == 6)
+            ms_iterate_d128_f16q_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        else if (g_ms_f16_cfg == 0)
+            ms_iterate_d128_f16q_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, 1, Q, partO, partS);
         else
         ms_iterate_d128_f16p_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
             X, blob, newX, bw, flags, N, 1, Q, partO, partS);
-        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, stream);
+        // the combine kernel sees the norm of every weighted mean: with heads-only weights it flags clouds whose means cancel
+        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, g_ms_f16_cfg == 0 ? lowq : nullptr, stream);
         if (rc != SED_OK) return rc;
     }
+    if (g_ms_f16_cfg == 0 && iters > 0)               // flagged clouds again, (h, l) weights, all iterations in one launch
+        ms_iterate_d128_f16q_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -2279,34 +2330,35 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
                   int** flags_out, hipStream_t stream) {
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes(B, N, g_ms_f16_cfg));
+    int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
     if (e != hipSuccess) return (int)e;
     if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
-    if (g_ms_f16_cfg == 0) return f16q_launch(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 0) return f16q_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 6) return f16q_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     if (g_ms_f16_cfg == 5) return f16r_launch(B, N, iters, bw, X, newX, blob, flags, stream);
     return g_ms_f16_cfg == 4 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
                              : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
 }
 
 
-static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
-
 // stage images of the sorted rows | flags | stage images of the tile references | scratch flags
 size_t ms_f16_sparse_workspace_bytes(int B, int N) {
     const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
-    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 2 * f16_flag_bytes(B);      // sized for either image format
+    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 3 * f16_flag_bytes(B);      // sized for either image format
 }
 
 // Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
 // row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated).
-// g_ms_f16_sparse_cfg: 1 = ms_iterate_d128_f16s_kernel (four-plane images, 3 buffers; default), 0 = ms_iterate_d128_f16t_kernel
+// g_ms_f16_sparse_cfg: 2 = ms_iterate_d128_f16s_kernel with fp16-head weights (5 MFMAs per block pair; default), 1 = the same with
+// (h, l) weights (6 MFMAs), 0 = ms_iterate_d128_f16t_kernel
 // (row-major-only stage images, transpose reads, 6 buffers: half the copy traffic, and 8 % slower -- 54.6 vs 50.5 ms on the
 // 64-cloud clustered benchmark: the copies are not what holds the sparse kernel)
-int g_ms_f16_sparse_cfg = 1;
+int g_ms_f16_sparse_cfg = 2;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, hipStream_t stream) {
@@ -2317,8 +2369,11 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     int* flags = (int*)(blob + f16_blob_bytes(B, N, cfg));
     uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
     int* flags2 = (int*)(refblob + f16_blob_bytes(B, nrs * 32, cfg));
+    int* lowq = (int*)((uint8_t*)flags2 + f16_flag_bytes(B));           // clouds whose weighted means cancel (heads-only pass)
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     if (g_ms_f16_sparse_cfg == 0) {
         using L = StageLayoutN;
@@ -2343,27 +2398,36 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
-    ms_iterate_d128_f16s_kernel<true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
-        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+    if (g_ms_f16_sparse_cfg == 2) {        // heads-only weights; flagged clouds again with (h, l) weights (not counted in stats)
+        ms_iterate_d128_f16s_kernel<true, false><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq);
+        ms_iterate_d128_f16s_kernel<true, true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq);
+    } else
+        ms_iterate_d128_f16s_kernel<true, true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
 
 extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
-    if (cfg < 0 || cfg > 1) return SED_EINVAL;
+    if (cfg < 0 || cfg > 2) return SED_EINVAL;
     g_ms_f16_sparse_cfg = cfg;
     return SED_OK;
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 5) return SED_EINVAL;
+    if (cfg < 0 || cfg > 6) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

@@ -121,6 +121,10 @@ def main(argv=None):
                          "unless this flag is given)")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="closed-form synthetic weights instead of the checkpoints named by the config (tests, benchmarks)")
+    ap.add_argument("--ms-weight-digits", type=int, choices=[1, 2], default=1,
+                    help="fp16 digits of the kernel weights in the mean-shift iterations' second product (sednet_hip.ops."
+                         "ms_set_weight_digits): 1 = fp16 heads (default, 5 MFMAs per block pair), 2 = (h, l) pairs, "
+                         "fp32-equivalent, 12 %% slower")
     args = ap.parse_args(argv)
     if not args.input and not args.synthetic:
         ap.error("give --input GLOB of .npz clouds (points, normals[, labels, primitives]) or --synthetic N")
@@ -133,6 +137,7 @@ def main(argv=None):
     model = build_model(config.knn, config.pretrain_model_path, 0, device, log, args.synthetic_weights)              # :191-193
     model_inst = build_model(config.knn, config.pretrain_model_type_path, 1, device, log, args.synthetic_weights)    # :196-198
     ms = MeanShift()
+    ops.ms_set_weight_digits(args.ms_weight_digits)
     x_all, labels_all, types_all, ids = load_clouds(args)
     if args.save == "Save":
         os.makedirs(args.out, exist_ok=True)

@@ -198,6 +198,20 @@ MS_SPARSE_SKIP = -30.0
 MS_SPARSE_MAX_NEAR = 0.3
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
 _MS_VARIANT = "auto"
+_MS_WEIGHT_DIGITS = 1
+
+
+def ms_set_weight_digits(digits):
+    """fp16 digits of the kernel weights in the split-fp16 mean-shift kernels' second product: 1 (default; fp16 heads only,
+    consistently in numerator and row sum: 5 MFMAs per block pair, rows within ~5e-7 of the exact fp32 kernel per iteration) or
+    2 ((h, l) pairs, 6 MFMAs, fp32-equivalent: ~1e-7; 12 % slower). Applies to the automatic schedule choice, dense and
+    block-sparse."""
+    global _MS_WEIGHT_DIGITS
+    if digits not in (1, 2):
+        raise ValueError("digits must be 1 or 2")
+    _MS_WEIGHT_DIGITS = digits
+    check(lib.sed_ms_set_f16_sparse_config(3 - digits), "ms_set_f16_sparse_config")
+    ms_set_variant(_MS_VARIANT)
 _PROBE_IDX = {}
 
 
@@ -394,11 +408,14 @@ def ms_set_variant(variant):
     """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
     "f16" (split-fp16 MFMA emulation, software-pipelined kernel; "f16c" = its key-chunked form for few clouds per call,
     "f16g" / "f16i" = the earlier pipelined kernel with wave groups half a block out of phase / in phase, "f16v1" / "f16b" =
-    the first, unpipelined version with 64-key / 32-key stages)."""
+    the first, unpipelined version with 64-key / 32-key stages). "f16" / "f16c" feed the weights into the second product and the
+    row sum as their fp16 heads only (5 MFMAs per block pair); "f16x" / "f16xc" = the same kernels with (h, l) weights (6 MFMAs),
+    like all the earlier versions."""
     global _MS_VARIANT
     _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
-    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5}.get(variant, 0)), "ms_set_f16_config")
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5}.get(variant, 4)),
+    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5, "f16x": 6, "f16xc": 6}.get(
+        variant, 0 if _MS_WEIGHT_DIGITS == 1 else 6)), "ms_set_f16_config")
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5, "f16xc": 5}.get(variant, 4)),
           "ms_set_variant")
 
 

@@ -39,17 +39,21 @@ def test_bandwidth_matches_golden_and_oracle(T, golden):
 def variant(request):
     """Force one of the two d = 128 iteration kernels for the test, restore the size-based choice after."""
     from sednet_hip import ops
-    if request.param == "sparse":            # the block-sparse split-fp16 schedule, forced (default: chosen per cloud)
+    from sednet_hip._lib import lib
+    if request.param in ("sparse", "sparsex"):   # the block-sparse split-fp16 schedule, forced (default: chosen per cloud)
         ops.ms_set_variant("auto")
         ops.MS_SPARSE = "on"
+        lib.sed_ms_set_f16_sparse_config(1 if request.param == "sparsex" else 2)    # (h, l) weights / fp16 heads
     else:
         ops.ms_set_variant(request.param)
     yield request.param
     ops.ms_set_variant("auto")
     ops.MS_SPARSE = "auto"
+    lib.sed_ms_set_f16_sparse_config(2)
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "sparse"],
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "f16x", "f16xc", "sparse",
+                                     "sparsex"],
                          indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
@@ -94,8 +98,9 @@ def test_mean_shift_end_to_end(T, golden):
 
 
 def test_iteration_variants_agree_at_full_size(T):
-    """The fp32 schedules differ only in summation order, the split-fp16 kernel in how the two products are evaluated
-    (3 fp16 MFMAs on exact (h, l) splits, fp32 accumulation): 10 000 points, ragged last tile, 3 clouds."""
+    """The fp32 schedules differ only in summation order, the split-fp16 kernels in how the two products are evaluated
+    ("f16x": 3 fp16 MFMAs on exact (h, l) splits per product, fp32 accumulation; "f16", the default: the second product with
+    the weights' fp16 heads only, consistently in numerator and row sum): 10 000 points, ragged last tile, 3 clouds."""
     from sednet_hip import ops, synth
     Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + c, sigma=0.02, seed=40 + c)[0]
                    for c in range(3)])
@@ -103,7 +108,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16i", "f16v1", "f16b", "f16c"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16x", "f16i", "f16v1", "f16b", "f16c", "f16xc"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -114,14 +119,23 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["f16"], res["splitk"], atol=2e-5)
-    np.testing.assert_array_equal(res["f16"], res["f16i"])           # same arithmetic and order, different schedule
-    np.testing.assert_array_equal(res["f16"], res["f16b"])
-    np.testing.assert_allclose(res["f16"], res["f16v1"], atol=2e-6)  # 32- vs 64-key stages: order of the backward sweeps
+    np.testing.assert_allclose(res["f16x"], res["splitk"], atol=2e-5)
+    np.testing.assert_allclose(res["f16"], res["f16x"], atol=3e-6)   # fp16-head weights vs (h, l) weights (measured 6e-7)
+    np.testing.assert_array_equal(res["f16x"], res["f16i"])          # same arithmetic and order, different schedule
+    np.testing.assert_array_equal(res["f16x"], res["f16b"])
+    np.testing.assert_allclose(res["f16x"], res["f16v1"], atol=2e-6) # 32- vs 64-key stages: order of the backward sweeps
     np.testing.assert_allclose(res["f16"], res["f16c"], atol=2e-5)   # key-chunked: partial sums added per chunk
+    np.testing.assert_allclose(res["f16x"], res["f16xc"], atol=2e-5)
+    try:                       # the user-facing knob selects the same kernels (3 clouds: the planner takes the key-chunked form)
+        ops.ms_set_weight_digits(2)
+        np.testing.assert_array_equal(ops._ms_iterate_dense(X, bw, 50).cpu().numpy(), res["f16xc"])
+    finally:
+        ops.ms_set_weight_digits(1)
+    np.testing.assert_array_equal(ops._ms_iterate_dense(X, bw, 50).cpu().numpy(), res["f16c"])
     assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16"]).all()
     one = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16x"):
             ops.ms_set_variant(v)
             one[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()
     finally:
@@ -136,8 +150,37 @@ def test_iteration_variants_agree_at_full_size(T):
     ref /= np.linalg.norm(ref, axis=1, keepdims=True)
     np.testing.assert_allclose(one["splitk"][0][rows], ref, atol=3e-6)
     np.testing.assert_allclose(one["f16"][0][rows], ref, atol=3e-6)
+    np.testing.assert_allclose(one["f16x"][0][rows], ref, atol=3e-6)
     np.testing.assert_allclose(one["chunked"][0][rows], ref, atol=5e-6)
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
+
+
+def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
+    """The default kernels feed the weights into the second product as fp16 heads; normalising a weighted mean of norm |o|
+    amplifies that rounding by 1 / |o|. Unstructured rows under a bandwidth that spans the cloud have |o| ~ 1 / sqrt(N): the
+    kernel flags such clouds (|o| < 1/2 in any iteration) and a second launch redoes them with (h, l) weights -- on the device,
+    per cloud, so the other clouds of the batch keep the bits they have alone."""
+    from sednet_hip import ops, synth
+    rnd = T.nn.functional.normalize(T.randn(2, 3000, 128, generator=T.Generator().manual_seed(1)), dim=2)
+    clu = T.from_numpy(synth.clustered_embedding(N=3000, d=128, n_clusters=7, sigma=0.02, seed=5)[0])[None]
+    X = T.cat([rnd[:1], clu, rnd[1:]]).cuda().contiguous()
+    bw = ops.ms_bandwidth(X, 45, 0.003)
+    res = {}
+    try:
+        for v in ("f16", "f16x", "f16c", "batched"):
+            ops.ms_set_variant(v)
+            res[v] = ops.ms_iterate(X, bw, 5).cpu().numpy()
+        ops.ms_set_variant("f16")
+        alone = ops.ms_iterate(X[1:2], bw[1:2], 5).cpu().numpy()[0]
+    finally:
+        ops.ms_set_variant("auto")
+    for c in (0, 2):                                    # flagged: exactly the (h, l)-weights kernel's rows, in both forms
+        np.testing.assert_array_equal(res["f16"][c], res["f16x"][c])
+        np.testing.assert_array_equal(res["f16c"][c], res["f16x"][c])
+        np.testing.assert_allclose(res["f16"][c], res["batched"][c], atol=2e-5)
+    assert (res["f16"][1] != res["f16x"][1]).any()                       # not flagged: the heads-only rows ...
+    np.testing.assert_array_equal(res["f16"][1], alone)                  # ... the same as without flagged neighbours
+    np.testing.assert_allclose(res["f16"][1], res["f16x"][1], atol=2e-6)
 
 
 def test_split_fp16_falls_back_for_non_unit_rows(T):
@@ -243,6 +286,8 @@ def test_block_sparse_schedule(T):
     # wider clusters (sigma = 0.04: neighbouring clusters overlap in angle, few blocks can be skipped) -- still the same rows
     Xw = dev(T, np.stack([synth.clustered_embedding(N=5000, d=128, n_clusters=20, sigma=0.04, seed=77)[0]]))
     bww = ops.ms_bandwidth(Xw, 75, 0.003)
+    # (b = 0.58 here: the other 19 clusters outweigh a point's own, the weighted means have norm ~0.4 -- every schedule flags
+    # the cloud and redoes it with (h, l) weights, see test_cancelling_weighted_means_are_redone_with_two_weight_digits)
     for f16 in (False, True):
         np.testing.assert_allclose(ops.ms_iterate_sparse(Xw, bww, 50, -30.0, f16=f16).cpu().numpy(),
                                    ops._ms_iterate_dense(Xw, bww, 50).cpu().numpy(), atol=3e-5)
@@ -339,7 +384,7 @@ def test_row_major_only_stage_images(T):
     X = dev(T, Xs)
     bw = ops.ms_bandwidth(X, 75, 0.003)
     try:
-        ops.ms_set_variant("f16")
+        ops.ms_set_variant("f16x")                               # the (h, l)-weights kernels: what the experimental ones compute
         ref = ops._ms_iterate_dense(X, bw, 20).cpu().numpy()
         ops.ms_set_variant("f16r")
         got = ops._ms_iterate_dense(X, bw, 20).cpu().numpy()
@@ -347,12 +392,13 @@ def test_row_major_only_stage_images(T):
         ops.ms_set_variant("auto")
     np.testing.assert_allclose(got, ref, atol=3e-6)
     st = [T.zeros(5, dtype=T.int64, device="cuda") for _ in range(2)]
-    sp = ops.ms_iterate_sparse(X, bw, 20, stats=st[0]).cpu().numpy()
     try:
+        check(lib.sed_ms_set_f16_sparse_config(1), "cfg")
+        sp = ops.ms_iterate_sparse(X, bw, 20, stats=st[0]).cpu().numpy()
         check(lib.sed_ms_set_f16_sparse_config(0), "cfg")
         sp_n = ops.ms_iterate_sparse(X, bw, 20, stats=st[1]).cpu().numpy()
     finally:
-        check(lib.sed_ms_set_f16_sparse_config(1), "cfg")
+        check(lib.sed_ms_set_f16_sparse_config(2), "cfg")
     np.testing.assert_allclose(sp_n, sp, atol=3e-6)
     np.testing.assert_allclose(sp_n, ref, atol=3e-6)
     a, b_ = st[0].cpu().numpy(), st[1].cpu().numpy()

@@ -26,7 +26,7 @@ def iterate(X, b, iters, mode, snaps):
         else:
             qh, ql = split16(Q, SX)
             acc = (ql.astype(np.float64) @ xh.T) + (qh.astype(np.float64) @ xl.T)
-            acc = acc.astype(F32) if mode == "f16x2" else acc
+            acc = acc.astype(F32) if mode.startswith("f16x2") else acc
             acc = acc + qh.astype(np.float64) @ xh.T
             s = (acc.astype(F32) * F32(2.0 ** -22)).astype(F32)
         if mode == "f64":
@@ -39,9 +39,15 @@ def iterate(X, b, iters, mode, snaps):
                 o = (p @ X).astype(F32); rs = p.sum(1, keepdims=True, dtype=F32)
             else:
                 ph, pl = split16(p, SP)
-                o = (pl.astype(np.float64) @ xh) + (ph.astype(np.float64) @ xl) + (ph.astype(np.float64) @ xh)
+                if mode.endswith("ph"):
+                    # 5-MFMA form: the weights enter both sums as their fp16 heads only (numerator and denominator
+                    # consistently), X keeps both digits
+                    o = (ph.astype(np.float64) @ xl) + (ph.astype(np.float64) @ xh)
+                    rs = (ph.astype(np.float64).sum(1, keepdims=True) * 2.0 ** -14).astype(F32)
+                else:
+                    o = (pl.astype(np.float64) @ xh) + (ph.astype(np.float64) @ xl) + (ph.astype(np.float64) @ xh)
+                    rs = ((ph.astype(np.float64) + pl).sum(1, keepdims=True) * 2.0 ** -14).astype(F32)
                 o = (o * 2.0 ** -25).astype(F32)
-                rs = ((ph.astype(np.float64) + pl).sum(1, keepdims=True) * 2.0 ** -14).astype(F32)
         if mode == "f64":
             nq = o / rs
             Q = (nq / np.linalg.norm(nq, axis=1, keepdims=True)).astype(F32)
@@ -55,9 +61,10 @@ if __name__ == "__main__":
     g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", sys.argv[1] if len(sys.argv) > 1 else "f_ms.npz"))
     X = g["X"]; b = max(float(g["bw_q05_ns2000"]) if "bw_q05_ns2000" in g.files else float(g["bw"]), 0.003)
     ref = {1: g["newX_it1"], 5: g["newX_it5"], 50: g["newX_it50"]}
-    res = {m: iterate(X, b, 50, m, ref) for m in ("f64", "f32", "f16x2")}
+    res = {m: iterate(X, b, 50, m, ref) for m in ("f64", "f32", "f16x2", "f16x2ph")}
     for it in (1, 5, 50):
         n = ref[it].shape[0]
         print(it, {m: float(np.abs(res[m][it][:n] - ref[it]).max()) for m in res},
               "f16x2 vs f64", float(np.abs(res["f16x2"][it] - res["f64"][it]).max()),
+              "f16x2ph vs f64", float(np.abs(res["f16x2ph"][it] - res["f64"][it]).max()),
               "f32 vs f64", float(np.abs(res["f32"][it] - res["f64"][it]).max()))

@@ -569,6 +569,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 // same three LDS buffers, same operand ring and the same MFMA order per accumulator as ms_iterate_d128_f16p_kernel (hence
 // the same bits); one barrier per block, placed after step 13 of the second product (the last step that still loads from
 // the block's buffer), after which block n + 3 is copied into that buffer.
+// (ring distance 3 was tried with the 5-MFMA form, whose second product issues one operand read per MFMA: the four extra
+// live operand registers spill inside the loop -- 836 instead of 337 ms)
 #ifndef F16Q_RING_DISTANCE
 #define F16Q_RING_DISTANCE 2
 #endif
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const floa
 // sum_j p_j e_j (x_j - o) / sum_j p_j ~ 2^-12 / sqrt(3) * (spread of the keys under the kernel) / sqrt(#effective keys):
 // 1e-7 .. 9e-7 on the golden snapshots (tools/f16split_emulation.py) against their 2e-6 / 5e-6 / 1e-5 tolerances. The first
 // product keeps its three terms: an error there is amplified by 1 / b^2.
-template <bool CHUNKED = false, bool PL = true>
+template <bool CHUNKED = false, bool PL = true, int RD_ = F16Q_RING_DISTANCE>
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const floa
                                                                       int* __restrict__ lowq = nullptr) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
-    constexpr int RD = F16Q_RING_DISTANCE;                // the operand ring runs RD steps ahead
+    constexpr int RD = RD_;                               // the operand ring runs RD steps ahead
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
     const int tid = threadIdx.x;
@@ -969,7 +971,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
                                                                       float* __restrict__ partS = nullptr) {
     using L = StageLayoutN;
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
-    constexpr int RD = F16Q_RING_DISTANCE;                // the operand ring runs RD steps ahead
+    constexpr int RD = F16Q_RING_DISTANCE;                              // the operand ring runs RD steps ahead
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
     const int tid = threadIdx.x;

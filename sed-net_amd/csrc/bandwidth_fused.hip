@@ -17,6 +17,7 @@
 // materialised path.
 #include "common.h"
 #include "split16.h"
+#include <type_traits>
 
 namespace {
 
@@ -143,29 +144,35 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
 #pragma unroll
             for (int g = 0; g < 4; ++g) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
         }
+        auto select = [&](auto ragged_c) {            // instantiated twice: only the last, partly filled tile tests for padding
+            constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
-            const float dv = 2.0f - dot2;                                                // mean_shift.py:128
-            const bool pad = ragged && tile * 32 + mfma_row(r, hi) >= N;
-            if (PASS == 1) {
-                float v = pad ? 3.0e38f : dv;
+            for (int r = 0; r < 16; ++r) {
+                const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
+                const float dv = 2.0f - dot2;                                                // mean_shift.py:128
+                const bool pad = RAGGED && ragged && tile * 32 + mfma_row(r, hi) >= N;
+                if (PASS == 1) {
+                    float v = pad ? 3.0e38f : dv;
 #pragma unroll
-                for (int i = 0; i < BM; ++i) {
-                    const float lo_ = fminf(bm[i][r], v);
-                    v = fmaxf(bm[i][r], v);
-                    bm[i][r] = lo_;
-                }
-            } else {
-                if (dv <= Tf && !pad) {
-                    const uint32_t key = f32_sortable(dv);
-                    if (key <= T) {
-                        if (cnt < CAPK) mylist[cnt] = key;
-                        ++cnt;
+                    for (int i = 0; i < BM; ++i) {
+                        const float lo_ = sed_vmin(bm[i][r], v);
+                        if (i + 1 < BM) v = sed_vmax(bm[i][r], v);
+                        bm[i][r] = lo_;
+                    }
+                } else {
+                    if (dv <= Tf && !pad) {
+                        const uint32_t key = f32_sortable(dv);
+                        if (key <= T) {
+                            if (cnt < CAPK) mylist[cnt] = key;
+                            ++cnt;
+                        }
                     }
                 }
             }
-        }
+        };
+        // (sweep 1 keeps ONE instantiation: with 128 bucket registers a second copy of the network makes the allocator spill)
+        if (PASS == 1 || ragged) select(std::true_type{});
+        else select(std::false_type{});
         if (tile + tstep < ntiles) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;

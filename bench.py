@@ -261,7 +261,7 @@ def main():
                        "ms_iterations": args.iterations, "embedding_dim": 128, "weights": "closed-form synthetic",
                        "parallelism": f"cloud-shard x{world}",
                        "mean_shift_passes_per_cloud": float(np.mean(out["passes"])) if world == 1 else None},
-            "roofline": {"kernel": "ms_iterate_d128_f16q_kernel" if split else "ms_iterate_d128_kernel", "bound": "mfma",
+            "roofline": {"kernel": "ms_iterate_d128_f16r_kernel<false, false>" if split else "ms_iterate_d128_kernel", "bound": "mfma",
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 3),
                          "flops_per_launch": flops_per_cloud * avg_clouds,

@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict
     if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
 }
 
-template <bool CHUNKED = false>
+template <bool CHUNKED = false, bool PL = true>      // PL: see ms_iterate_d128_f16q_kernel
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
@@ -968,7 +968,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
                                                                       const int* __restrict__ flags, int N, int iters,
                                                                       const float* __restrict__ Qin = nullptr,
                                                                       float* __restrict__ partO = nullptr,
-                                                                      float* __restrict__ partS = nullptr) {
+                                                                      float* __restrict__ partS = nullptr,
+                                                                      int* __restrict__ lowq = nullptr) {
     using L = StageLayoutN;
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int RD = F16Q_RING_DISTANCE;                              // the operand ring runs RD steps ahead
@@ -980,6 +981,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
     int bx;
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;
     const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
     const int nst = (N + 31) >> 5;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
@@ -1145,12 +1147,16 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
                 const int r = 2 * t + u;
                 p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
                 if (decltype(tail_c)::value && key0 + sigma_row(mfma_row(r, hi)) >= N) p[u] = 0.f;
-                rsum += p[u];
+                if (PL) rsum += p[u];
             }
             const h16x2 h = {(h16)p[0], (h16)p[1]};
-            const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
             phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
-            plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            if (PL) {
+                const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+                plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            } else {
+                rsum += (float)h[0] + (float)h[1];
+            }
         };
 
         // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
@@ -1199,9 +1205,11 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
         for (int t = 8; t < 16; ++t) {
             const int c = (t - 8) >> 1, j = (t - 8) & 1;
             const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
-            const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
             o[c] = mfma16(fb[t & 3], phj, o[c]);
-            o[c] = mfma16(fa[t & 3], plj, o[c]);
+            if (PL) {
+                const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+                o[c] = mfma16(fa[t & 3], plj, o[c]);
+            }
             o[c] = mfma16(fa[t & 3], phj, o[c]);
             if (t + RD < 16) ring_load(t + RD, base);
             else if (n + 2 < total) ring_load(t + RD - 16, n2base);
@@ -1252,6 +1260,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
             }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
         if (n == total - 1) {
             if (qrow < N) {
                 float* out = newX + ((size_t)cloud * N + qrow) * 128;
@@ -2145,8 +2154,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
 }  // namespace
 
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
-// cfg 0: software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1) with fp16-head weights
-// in the second product (5 MFMAs per block pair; default); 6: the same kernel with (h, l) weights (6 MFMAs);
+// cfg 0 (default): software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1) with fp16-head
+// weights in the second product (5 MFMAs per block pair) -- on row-major-only stage images (ms_iterate_d128_f16r_kernel, 17 KiB
+// per stage, transpose reads) in its one-launch form, on four-plane images (ms_iterate_d128_f16q_kernel) in its key-chunked
+// form; 7: the four-plane kernel in both forms; 6 / 5: four-plane / row-major kernel with (h, l) weights (6 MFMAs);
 // 1: round-2 pipelined kernel, wave groups in phase; 4: the same, groups half a block out of phase (the default until the
 // software-pipelined kernel); 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave
 // workgroups per CU
@@ -2154,16 +2165,20 @@ int g_ms_f16_cfg = 0;
 
 static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
 
-static size_t f16_blob_bytes(int B, int N, int cfg) {
-    const size_t kt = cfg == 2 ? 64 : 32;
-    const size_t stage = cfg == 2 ? StageLayout<64>::STAGE : cfg == 5 ? StageLayoutN::STAGE : StageLayout<32>::STAGE;
+// image formats: 0 = four planes, 32-key stages (StageLayout<32>); 2 = four planes, 64-key stages; 5 = row-major only (StageLayoutN)
+static size_t f16_blob_bytes(int B, int N, int fmt) {
+    const size_t kt = fmt == 2 ? 64 : 32;
+    const size_t stage = fmt == 2 ? StageLayout<64>::STAGE : fmt == 5 ? StageLayoutN::STAGE : StageLayout<32>::STAGE;
     return (size_t)B * ((N + kt - 1) / kt) * stage;
 }
+// format the one-launch (unchunked) kernel of a configuration reads; the key-chunked form always reads format 0
+static int f16_unchunked_fmt(int cfg) { return cfg == 2 ? 2 : (cfg == 0 || cfg == 5) ? 5 : 0; }
 
 // stage images | "rows not unit" flags | "weighted means cancel" flags (both per cloud, 256-byte blocks)
 size_t ms_f16_workspace_bytes(int B, int N) {
-    return f16_blob_bytes(B, N, g_ms_f16_cfg) + 2 * ((((size_t)B * sizeof(int) + 255) / 256) * 256);
+    return f16_blob_bytes(B, N, f16_unchunked_fmt(g_ms_f16_cfg)) + 2 * ((((size_t)B * sizeof(int) + 255) / 256) * 256);
 }
+static size_t f16_chunked_base_bytes(int B, int N) { return f16_blob_bytes(B, N, 0) + 2 * f16_flag_bytes(B); }
 
 template <int KT_, int NW>
 static int f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
@@ -2239,20 +2254,27 @@ static int f16q_launch(int B, int N, int iters, const float* bw, const float* X,
     return SED_OK;
 }
 
+template <bool PL>
 static int f16r_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
-                       hipStream_t stream) {
+                       int* lowq, hipStream_t stream) {
     using L = StageLayoutN;
     const int nst = (N + 31) / 32;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false>,
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, PL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
-    ms_iterate_d128_f16r_kernel<false><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N,
-                                                                                                 iters);
+    ms_iterate_d128_f16r_kernel<false, PL><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, PL ? nullptr : lowq);
+    if (!PL)
+        ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -2268,7 +2290,7 @@ int ms_f16_chunks(int N) {
 }
 
 size_t ms_f16_chunked_workspace_bytes(int B, int N) {
-    return ms_f16_workspace_bytes(B, N) + (size_t)B * N * ms_f16_chunks(N) * 129 * sizeof(float) + 256;
+    return f16_chunked_base_bytes(B, N) + (size_t)B * N * ms_f16_chunks(N) * 129 * sizeof(float) + 256;
 }
 
 // one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher
@@ -2280,7 +2302,7 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
     const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
-    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + ms_f16_workspace_bytes(B, N)) + 255) & ~(uintptr_t)255);
+    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + f16_chunked_base_bytes(B, N)) + 255) & ~(uintptr_t)255);
     float* partS = partO + (size_t)B * N * S * 128;
     int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
@@ -2305,22 +2327,23 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    const bool heads = g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7;
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
         if (g_ms_f16_cfg == 6)
             ms_iterate_d128_f16q_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, 1, Q, partO, partS);
-        else if (g_ms_f16_cfg == 0)
+        else if (g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7)
             ms_iterate_d128_f16q_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, 1, Q, partO, partS);
         else
         ms_iterate_d128_f16p_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
             X, blob, newX, bw, flags, N, 1, Q, partO, partS);
         // the combine kernel sees the norm of every weighted mean: with heads-only weights it flags clouds whose means cancel
-        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, g_ms_f16_cfg == 0 ? lowq : nullptr, stream);
+        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, heads ? lowq : nullptr, stream);
         if (rc != SED_OK) return rc;
     }
-    if (g_ms_f16_cfg == 0 && iters > 0)               // flagged clouds again, (h, l) weights, all iterations in one launch
+    if (heads && iters > 0)                           // flagged clouds again, (h, l) weights, all iterations in one launch
         ms_iterate_d128_f16q_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
             X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
     SED_LAUNCH_CHECK();
@@ -2331,16 +2354,17 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                   int** flags_out, hipStream_t stream) {
     uint8_t* blob = (uint8_t*)workspace;
-    int* flags = (int*)(blob + f16_blob_bytes(B, N, g_ms_f16_cfg));
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, f16_unchunked_fmt(g_ms_f16_cfg)));
     int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
     if (e != hipSuccess) return (int)e;
     if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
-    if (g_ms_f16_cfg == 0) return f16q_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 0) return f16r_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 7) return f16q_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     if (g_ms_f16_cfg == 6) return f16q_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
-    if (g_ms_f16_cfg == 5) return f16r_launch(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 5) return f16r_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     return g_ms_f16_cfg == 4 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
                              : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
 }
@@ -2429,7 +2453,7 @@ extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 6) return SED_EINVAL;
+    if (cfg < 0 || cfg > 7) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

@@ -52,8 +52,8 @@ def variant(request):
     lib.sed_ms_set_f16_sparse_config(2)
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "f16x", "f16xc", "sparse",
-                                     "sparsex"],
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "f16q", "f16x", "f16xc",
+                                     "sparse", "sparsex"],
                          indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
@@ -99,8 +99,9 @@ def test_mean_shift_end_to_end(T, golden):
 
 def test_iteration_variants_agree_at_full_size(T):
     """The fp32 schedules differ only in summation order, the split-fp16 kernels in how the two products are evaluated
-    ("f16x": 3 fp16 MFMAs on exact (h, l) splits per product, fp32 accumulation; "f16", the default: the second product with
-    the weights' fp16 heads only, consistently in numerator and row sum): 10 000 points, ragged last tile, 3 clouds."""
+    ("f16x" / "f16r": 3 fp16 MFMAs on exact (h, l) splits per product, fp32 accumulation, on four-plane / row-major-only stage
+    images; "f16q" / "f16", the default: the second product with the weights' fp16 heads only, consistently in numerator and
+    row sum): 10 000 points, ragged last tile, 3 clouds."""
     from sednet_hip import ops, synth
     Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + c, sigma=0.02, seed=40 + c)[0]
                    for c in range(3)])
@@ -108,7 +109,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16x", "f16i", "f16v1", "f16b", "f16c", "f16xc"):
+        for v in ("batched", "splitk", "chunked", "f16", "f16q", "f16r", "f16x", "f16i", "f16v1", "f16b", "f16c", "f16xc"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -120,7 +121,9 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["f16"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["f16x"], res["splitk"], atol=2e-5)
-    np.testing.assert_allclose(res["f16"], res["f16x"], atol=3e-6)   # fp16-head weights vs (h, l) weights (measured 6e-7)
+    np.testing.assert_allclose(res["f16"], res["f16r"], atol=3e-6)   # fp16-head weights vs (h, l) weights (measured 6e-7),
+    np.testing.assert_allclose(res["f16q"], res["f16x"], atol=3e-6)  # ... on row-major-only and on four-plane stage images
+    np.testing.assert_allclose(res["f16"], res["f16q"], atol=5e-6)   # the two image formats: key order inside a stage
     np.testing.assert_array_equal(res["f16x"], res["f16i"])          # same arithmetic and order, different schedule
     np.testing.assert_array_equal(res["f16x"], res["f16b"])
     np.testing.assert_allclose(res["f16x"], res["f16v1"], atol=2e-6) # 32- vs 64-key stages: order of the backward sweeps
@@ -167,20 +170,21 @@ def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
     bw = ops.ms_bandwidth(X, 45, 0.003)
     res = {}
     try:
-        for v in ("f16", "f16x", "f16c", "batched"):
+        for v in ("f16", "f16r", "f16q", "f16x", "f16c", "batched"):
             ops.ms_set_variant(v)
             res[v] = ops.ms_iterate(X, bw, 5).cpu().numpy()
         ops.ms_set_variant("f16")
         alone = ops.ms_iterate(X[1:2], bw[1:2], 5).cpu().numpy()[0]
     finally:
         ops.ms_set_variant("auto")
-    for c in (0, 2):                                    # flagged: exactly the (h, l)-weights kernel's rows, in both forms
-        np.testing.assert_array_equal(res["f16"][c], res["f16x"][c])
+    for c in (0, 2):                # flagged: exactly the rows of the (h, l)-weights kernel on the same stage images, in every form
+        np.testing.assert_array_equal(res["f16"][c], res["f16r"][c])
+        np.testing.assert_array_equal(res["f16q"][c], res["f16x"][c])
         np.testing.assert_array_equal(res["f16c"][c], res["f16x"][c])
         np.testing.assert_allclose(res["f16"][c], res["batched"][c], atol=2e-5)
-    assert (res["f16"][1] != res["f16x"][1]).any()                       # not flagged: the heads-only rows ...
+    assert (res["f16"][1] != res["f16r"][1]).any()                       # not flagged: the heads-only rows ...
     np.testing.assert_array_equal(res["f16"][1], alone)                  # ... the same as without flagged neighbours
-    np.testing.assert_allclose(res["f16"][1], res["f16x"][1], atol=2e-6)
+    np.testing.assert_allclose(res["f16"][1], res["f16r"][1], atol=2e-6)
 
 
 def test_split_fp16_falls_back_for_non_unit_rows(T):

@@ -59,11 +59,29 @@ with open(os.path.join(P, f"{tag}_pmc_kernels.md"), "w") as f:
     f.write(open(os.path.join(O, "pmc_kernels_msstage.md")).read())
 with open(os.path.join(P, f"{tag}_sparse_and_gemm_tools.md"), "w") as f:
     f.write(f"# Tool outputs (1 x MI355X, round 2, commit {commit})\n")
-    for name in ("sparse_check", "sparse_breakdown", "pointwise_bench"):
+    for name in ("sparse_check", "sparse_breakdown", "pointwise_bench", "f16h_check"):
+        if not os.path.exists(os.path.join(O, name + ".out")):
+            continue
         txt = [l for l in open(os.path.join(O, name + ".out")).read().splitlines() if "amdgpu.ids" not in l]
-        f.write(f"\n## tools/{ {'sparse_check': 'ms_sparse_f16_check.py 64', 'sparse_breakdown': 'ms_sparse_breakdown.py 64', 'pointwise_bench': 'pointwise_bench.py'}[name] }\n\n```\n" + "\n".join(txt) + "\n```\n")
+        f.write(f"\n## tools/{ {'sparse_check': 'ms_sparse_f16_check.py 64', 'sparse_breakdown': 'ms_sparse_breakdown.py 64', 'pointwise_bench': 'pointwise_bench.py', 'f16h_check': 'ms_f16h_check.py 64'}[name] }\n\n```\n" + "\n".join(txt) + "\n```\n")
 if os.path.exists(os.path.join(O, "pmc_f16_summary.md")):
     open(os.path.join(P, f"{tag}_pmc_ms_iterate_f16.md"), "w").write(
-        f"# PMC summary of ms_iterate_d128_f16p_kernel: `python tools/ms_iter_only.py 64 50 128 f16` (commit {commit})\n\n"
-        + open(os.path.join(O, "pmc_f16_summary.md")).read())
+        f"# PMC summary of ms_iterate_d128_f16r_kernel<false, false> (the default dense kernel): `python tools/ms_iter_only.py 64 50 128 f16` "
+        f"(SQ passes: 10 iterations) (commit {commit})\n\n" + open(os.path.join(O, "pmc_f16_summary.md")).read())
+    # HBM-side traffic record bench.py stamps into roofline.traffic (separate FETCH_SIZE / WRITE_SIZE passes of the 50-iteration launch)
+    vals = {}
+    for line in open(os.path.join(O, "pmc_f16_summary.md")):
+        c = [x.strip() for x in line.split("|")]
+        if len(c) >= 3 and c[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[c[1]] = float(c[2])
+    if len(vals) == 2:
+        json.dump({"kernel": "ms_iterate_d128_f16r_kernel<false, false>", "schedule": "split-fp16", "clouds": 64, "iterations": 50,
+                   "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                   "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+                   "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE reports half of a wide coalesced read, "
+                              "MI355X_MICROARCH.md section HBM; Infinity-Cache hits are counted)",
+                   "algorithmic_bytes_per_launch": 64 * 2 * 10000 * 128 * 4,
+                   "command": "python tools/ms_iter_only.py 64 50 128 f16", "commit": commit,
+                   "date": f"round 2, tools/profile_round.sh (profiles/{tag}_pmc_ms_iterate_f16.md)"},
+                  open(os.path.join(P, f"{tag}_pmc_ms_iterate.json"), "w"), indent=1)
 print("written:", sorted(x for x in os.listdir(P) if x.startswith(tag)))

@@ -307,9 +307,11 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
 }
 
 // ---- finalize: one wave per query, rank sort of the short candidate list ------------------------------------------
+// The candidates live in registers (lane e of chunk t holds candidate 64 t + e; <= 3 chunks = 2 CAPL) and are broadcast with
+// v_readlane: no LDS round trip per comparison (the LDS version spent its time in 60 dependent ds_read latencies per row).
+// rank = number of candidates that sort before mine by (key, index); ranks are distinct, the k smallest are written in order.
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restrict__ lists, const int* __restrict__ counts,
                                                            int k, size_t rows, int* __restrict__ idx_out) {
-    __shared__ Cand cs[4][2 * CAPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t row = (size_t)blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -317,23 +319,41 @@ __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restric
     c0 = c0 < CAPL * 2 ? c0 : CAPL * 2;                 // pn kernel packs everything into the first half-list pair
     c1 = c1 < CAPL ? c1 : CAPL;
     if (c1 > 0 && c0 > CAPL) c0 = CAPL;
-    const int C = c0 + c1;
+    const int C = __builtin_amdgcn_readfirstlane(c0 + c1);
     const Cand* l0 = lists + row * 2 * CAPL;
     const Cand* l1 = l0 + CAPL;
-    Cand* cw = cs[wave];
-    for (int e = lane; e < C; e += 64) cw[e] = e < c0 ? l0[e] : l1[e - c0];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    int* out = idx_out + row * k;
-    for (int e = lane; e < C; e += 64) {
-        const Cand me = cw[e];
-        int rank = 0;
-        for (int j = 0; j < C; ++j) {
-            const Cand o = cw[j];
-            rank += (o.key < me.key) || (o.key == me.key && o.idx < me.idx);
-        }
-        if (rank < k) out[rank] = me.idx;
+    constexpr int NCH = (2 * CAPL + 63) / 64;
+    uint32_t key[NCH];
+    int idx[NCH], rank[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const int e = lane + 64 * t;
+        Cand c;
+        c.key = 0xFFFFFFFFu; c.idx = 0x7FFFFFFF;
+        if (e < C) c = e < c0 ? l0[e] : l1[e - c0];
+        key[t] = c.key; idx[t] = c.idx; rank[t] = 0;
     }
+    auto against_chunk = [&](int t2, auto nch_c) {        // ranks of the first NCT chunks against the candidates of chunk t2
+        constexpr int NCT = decltype(nch_c)::value;
+        const int n2 = C - 64 * t2 < 64 ? C - 64 * t2 : 64;
+        for (int j = 0; j < n2; ++j) {
+            const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)key[t2], j);
+            const int oi = __builtin_amdgcn_readlane(idx[t2], j);
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) rank[t] += (ok < key[t]) || (ok == key[t] && oi < idx[t]);
+        }
+    };
+    if (C <= 64) {
+        against_chunk(0, std::integral_constant<int, 1>{});
+    } else {
+#pragma unroll
+        for (int t2 = 0; t2 < NCH; ++t2)
+            if (C > 64 * t2) against_chunk(t2, std::integral_constant<int, NCH>{});
+    }
+    int* out = idx_out + row * k;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t)
+        if (lane + 64 * t < C && rank[t] < k) out[rank[t]] = idx[t];
 }
 
 int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 -> 1, 32 -> 2, 64 -> 3, 85 -> 4)

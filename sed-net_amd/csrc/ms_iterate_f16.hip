@@ -920,7 +920,8 @@ struct StageLayoutN {
     static constexpr int XROW = 272, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, STAGE = 2 * XPLANE;   // 17408 B
     static_assert(STAGE % 1024 == 0, "whole DMA pieces");
 };
-__host__ __device__ constexpr int sigma_row(int m) { return 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1); }
+// accumulator row m = 16 a + 4 b + c  <->  image row sigma(m) = 16 a + 4 c + b (a 4 x 4 transpose inside every group of 16 rows)
+__host__ __device__ constexpr int sigma_row(int m) { return 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3); }
 
 // X [B, N, 128] fp32 -> row-major stage images [B, nst, 17408] (h plane | l plane, rows = keys in natural order, 272 B apart)
 __global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict__ X, const float* __restrict__ bw,
@@ -1057,21 +1058,25 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
     // Per-lane LDS offsets of the operand reads (recomputed per block from a lane id the compiler cannot hoist: invariants
     // that live across the register-hungry row update end up in scratch, and a reload's vmcnt wait in the hot loop also waits
     // for the stage copy in flight).
-    //   first product: accumulator row m reads image row sigma(m), sigma(4 a + b) = 8 (a >> 1) + 2 b + (a & 1) -- a
-    //     permutation inside each group of 8 rows, conflict-free for ds_read_b128 like the identity, chosen so that
-    //   second product: the four keys of one transpose read (accumulator rows rho .. rho + 3) sit in image rows two apart
-    //     (8 banks): ds_read_b64_tr_b16 -- every lane passes the address of 4 consecutive features of one key, a 16-lane
-    //     group gets back the 4 keys x 16 features block transposed: lane = feature, 4 keys -- is then conflict-free on the
-    //     SAME row-major planes the first product reads. No transposed planes in the image: 17 KiB per stage instead of 37.
+    //   first product: accumulator row m reads image row sigma(m), sigma(16 a + 4 b + c) = 16 a + 4 c + b -- a permutation
+    //     inside each group of 16 rows, conflict-free for ds_read_b128 (its four 16-lane groups see 16 distinct rows mod 16,
+    //     272-byte rows = 4 banks apart), chosen so that
+    //   second product: the four keys of one transpose read (accumulator rows rho .. rho + 3) sit in image rows FOUR apart
+    //     (16 banks): ds_read_b64_tr_b16 -- every lane passes the address of 4 consecutive features of one key, a 16-lane
+    //     group gets back the 4 keys x 16 features block transposed: lane = feature, 4 keys. Its conflict groups are the two
+    //     32-lane halves: lanes 0-15 (features 0-15 of the tile) and 16-31 (features 16-31, 8 banks further) read the same
+    //     four rows, so rows 16 banks apart make the 64 dwords of a half distinct. (The first version put the rows two
+    //     apart, 8 banks: lanes 16-31 then collided with the next row of lanes 0-15 -- SQ_LDS_BANK_CONFLICT 1.3 extra cycles
+    //     per LDS instruction, a third of the LDS-array cycles.) No transposed planes in the image: 17 KiB per stage instead of 37.
     int xoff, toff;
     auto refresh_offsets = [&]() {
         int l;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         const int m = l & 31, h = l >> 5;
-        const int sig = 8 * (m >> 3) + 2 * (m & 3) + ((m >> 2) & 1);
+        const int sig = 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3);
         xoff = sig * XROW + h * 16;
         const int i16 = l & 15;
-        toff = (2 * (i16 >> 2) + h) * XROW + 32 * ((l >> 4) & 1) + 8 * (i16 & 3);
+        toff = (4 * (i16 >> 2) + h) * XROW + 32 * ((l >> 4) & 1) + 8 * (i16 & 3);
     };
     refresh_offsets();
     typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
@@ -1079,7 +1084,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
         const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 8) * XROW + 64 * c));
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
         typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
         const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(h16x8, both);
@@ -1838,13 +1843,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
     h16x8 fa[4], fb[4];
     // row sigma(li) of the image for the first product, transpose reads for the second: see ms_iterate_d128_f16r_kernel
     const int xoff = sigma_row(li) * XROW + hi * 16;
-    const int toff = (2 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    const int toff = (4 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
     typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
     auto tr8 = [&](const uint8_t* plane, int c, int j) {
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
         const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 8) * XROW + 64 * c));
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
         typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
         const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(h16x8, both);

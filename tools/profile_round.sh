@@ -18,7 +18,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python $R/tools/ms_iter_only.py 64 50 128 f16 > $O/pmc_$C.log 2>&1
 done
 bash $R/tools/pmc_f16.sh f16 prof_$TAG/pmc_sq > /dev/null 2>&1
-python $R/tools/pmc_summary.py f16r_kernel $O/pmc_f16_summary.md $(find $O/pmc_sq $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*counter_collection.csv" -printf "%h\n" | sort -u)
+python $R/tools/pmc_summary.py "f16r_kernel<false, false>" $O/pmc_f16_summary.md $(find $O/pmc_sq $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE -name "*counter_collection.csv" -printf "%h\n" | sort -u)
 # per-kernel PMC table: one bench step (headline) and one clustering stage on planted embeddings (block-sparse kernel)
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $O/pk_bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-k64 --no-realistic > $O/pk_bench.out 2> $O/pk_bench.err

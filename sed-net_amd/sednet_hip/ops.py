@@ -370,8 +370,17 @@ def ms_iterate(X, bw, iters):
     if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D == 128 and iters > 0 and 1024 <= N <= 16384:
         if MS_SPARSE == "on":
             return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+        if B == 1:
+            # one cloud per call (how the reference script runs): its 40 workgroups leave the block-sparse kernel one round
+            # of 7.4 ms + 1.7 ms of preparation on 16 % of the CUs, the key-chunked dense schedule takes 7.0 ms on all of them
+            # (tools/one_cloud_profile.sh) -- and the density probe with its D->H copy is not needed at all
+            MS_SPARSE_STATS["dense_clouds"] += 1
+            return _ms_iterate_dense(X, bw, iters)
         sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < MS_SPARSE_MAX_NEAR).cpu()       # one small D->H copy
         ns = int(sparse.sum())
+        if ns == 1:                                 # a single clustered cloud in the batch: the same argument
+            sparse[:] = False
+            ns = 0
         MS_SPARSE_STATS["sparse_clouds"] += ns
         MS_SPARSE_STATS["dense_clouds"] += B - ns
         if ns == B:

@@ -310,50 +310,78 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
 // The candidates live in registers (lane e of chunk t holds candidate 64 t + e; <= 3 chunks = 2 CAPL) and are broadcast with
 // v_readlane: no LDS round trip per comparison (the LDS version spent its time in 60 dependent ds_read latencies per row).
 // rank = number of candidates that sort before mine by (key, index); ranks are distinct, the k smallest are written in order.
+constexpr int FIN_ROWS = 4;                        // rows per wave: all their loads are in flight before the first rank loop
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restrict__ lists, const int* __restrict__ counts,
                                                            int k, size_t rows, int* __restrict__ idx_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t row = (size_t)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    int c0 = counts[row * 2], c1 = counts[row * 2 + 1];
-    c0 = c0 < CAPL * 2 ? c0 : CAPL * 2;                 // pn kernel packs everything into the first half-list pair
-    c1 = c1 < CAPL ? c1 : CAPL;
-    if (c1 > 0 && c0 > CAPL) c0 = CAPL;
-    const int C = __builtin_amdgcn_readfirstlane(c0 + c1);
-    const Cand* l0 = lists + row * 2 * CAPL;
-    const Cand* l1 = l0 + CAPL;
+    const size_t row0 = ((size_t)blockIdx.x * 4 + wave) * FIN_ROWS;
+    if (row0 >= rows) return;
     constexpr int NCH = (2 * CAPL + 63) / 64;
-    uint32_t key[NCH];
-    int idx[NCH], rank[NCH];
+    int c0[FIN_ROWS], C[FIN_ROWS];
 #pragma unroll
-    for (int t = 0; t < NCH; ++t) {
-        const int e = lane + 64 * t;
-        Cand c;
-        c.key = 0xFFFFFFFFu; c.idx = 0x7FFFFFFF;
-        if (e < C) c = e < c0 ? l0[e] : l1[e - c0];
-        key[t] = c.key; idx[t] = c.idx; rank[t] = 0;
+    for (int q = 0; q < FIN_ROWS; ++q) {
+        const size_t row = row0 + q < rows ? row0 + q : rows - 1;
+        int a = counts[row * 2], b = counts[row * 2 + 1];
+        a = a < CAPL * 2 ? a : CAPL * 2;                // pn kernel packs everything into the first half-list pair
+        b = b < CAPL ? b : CAPL;
+        if (b > 0 && a > CAPL) a = CAPL;
+        c0[q] = a;
+        C[q] = row0 + q < rows ? a + b : 0;
     }
-    auto against_chunk = [&](int t2, auto nch_c) {        // ranks of the first NCT chunks against the candidates of chunk t2
-        constexpr int NCT = decltype(nch_c)::value;
-        const int n2 = C - 64 * t2 < 64 ? C - 64 * t2 : 64;
-        for (int j = 0; j < n2; ++j) {
-            const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)key[t2], j);
-            const int oi = __builtin_amdgcn_readlane(idx[t2], j);
+    uint32_t key[FIN_ROWS][NCH];                        // (key, index) compared as ONE 64-bit number: key in the high word
+    int idx[FIN_ROWS][NCH];
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) rank[t] += (ok < key[t]) || (ok == key[t] && oi < idx[t]);
+    for (int q = 0; q < FIN_ROWS; ++q) {
+        const size_t row = row0 + q < rows ? row0 + q : rows - 1;
+        const Cand* l0 = lists + row * 2 * CAPL;
+        const Cand* l1 = l0 + CAPL;
+        const int Cu = __builtin_amdgcn_readfirstlane(C[q]);
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            // unconditional loads from clamped positions (the lists are allocated in full), selected afterwards: no divergent
+            // branch, so the loads of all rows are in flight together; chunks beyond the row's count are skipped uniformly
+            const int e = lane + 64 * t;
+            key[q][t] = 0xFFFFFFFFu; idx[q][t] = 0x7FFFFFFF;
+            if (64 * t < Cu) {
+                const bool ok = e < Cu;
+                const int ec = ok ? e : 0;
+                const Cand c = ec < c0[q] ? l0[ec] : l1[ec - c0[q]];
+                key[q][t] = ok ? c.key : 0xFFFFFFFFu;
+                idx[q][t] = ok ? c.idx : 0x7FFFFFFF;
+            }
         }
-    };
-    if (C <= 64) {
-        against_chunk(0, std::integral_constant<int, 1>{});
-    } else {
-#pragma unroll
-        for (int t2 = 0; t2 < NCH; ++t2)
-            if (C > 64 * t2) against_chunk(t2, std::integral_constant<int, NCH>{});
     }
-    int* out = idx_out + row * k;
 #pragma unroll
-    for (int t = 0; t < NCH; ++t)
-        if (lane + 64 * t < C && rank[t] < k) out[rank[t]] = idx[t];
+    for (int q = 0; q < FIN_ROWS; ++q) {
+        const int Cq = __builtin_amdgcn_readfirstlane(C[q]);
+        if (Cq == 0) continue;
+        int rank[NCH];
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) rank[t] = 0;
+        auto against_chunk = [&](int t2, auto nch_c) {    // ranks of the first NCT chunks against the candidates of chunk t2
+            constexpr int NCT = decltype(nch_c)::value;
+            const int n2 = Cq - 64 * t2 < 64 ? Cq - 64 * t2 : 64;
+            for (int j = 0; j < n2; ++j) {
+                const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)key[q][t2], j);
+                const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane(idx[q][t2], j);
+                const unsigned long long o64 = ((unsigned long long)ok << 32) | oi;
+#pragma unroll
+                for (int t = 0; t < NCT; ++t)
+                    rank[t] += o64 < (((unsigned long long)key[q][t] << 32) | (uint32_t)idx[q][t]) ? 1 : 0;
+            }
+        };
+        if (Cq <= 64) {
+            against_chunk(0, std::integral_constant<int, 1>{});
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < NCH; ++t2)
+                if (Cq > 64 * t2) against_chunk(t2, std::integral_constant<int, NCH>{});
+        }
+        int* out = idx_out + (row0 + q) * k;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t)
+            if (lane + 64 * t < Cq && rank[t] < k) out[rank[t]] = idx[q][t];
+    }
 }
 
 int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 -> 1, 32 -> 2, 64 -> 3, 85 -> 4)
@@ -463,7 +491,7 @@ static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int
     }
     if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();
-    knn_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows, idx);
+    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows, idx);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -497,7 +525,7 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
-    knn_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, k, rows, idx);
+    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, rows, idx);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

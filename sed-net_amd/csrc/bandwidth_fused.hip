@@ -204,31 +204,37 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     }
 }
 
-// one wave per query: exact K-th smallest of its candidates (<= 2 CAPK keys). grid ceil(rows / 4), block 256
+// one wave per query: exact K-th smallest of its candidates (<= 2 CAPK keys). grid ceil(rows / 4), block 256.
+// Counting is ballot + popcount (uniform, no cross-lane shuffles); the loads are unconditional from clamped positions and
+// skipped uniformly for the 64-entry chunks beyond a list's count, so all of a row's loads are in flight together.
 __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __restrict__ lists,
                                                               const int* __restrict__ counts, int K, size_t rows,
                                                               float* __restrict__ kth) {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const int c0 = min(counts[row * 2], CAPK), c1 = min(counts[row * 2 + 1], CAPK);
+    const int c0 = __builtin_amdgcn_readfirstlane(min(counts[row * 2], CAPK));
+    const int c1 = __builtin_amdgcn_readfirstlane(min(counts[row * 2 + 1], CAPK));
     const uint32_t* l0 = lists + row * 2 * CAPK;
-    uint32_t v[2 * CAPK / 64];
+    constexpr int HC = CAPK / 64;                     // 64-entry chunks per half-list
+    uint32_t v[2 * HC];
 #pragma unroll
-    for (int u = 0; u < 2 * CAPK / 64; ++u) {
-        const int i = lane + 64 * u;                  // 0 .. 2 CAPK - 1: first half = lane-0 list, second = lane-1 list
-        const bool ok = i < CAPK ? i < c0 : i - CAPK < c1;
-        v[u] = ok ? l0[i] : 0xFFFFFFFFu;
+    for (int u = 0; u < 2 * HC; ++u) {
+        const int cu = u < HC ? c0 : c1;              // count of the half-list this chunk belongs to
+        const int i = lane + 64 * (u % HC);           // position inside the half-list
+        v[u] = 0xFFFFFFFFu;
+        if (64 * (u % HC) < cu) {
+            const uint32_t x = l0[(u < HC ? 0 : CAPK) + (i < cu ? i : 0)];
+            v[u] = i < cu ? x : 0xFFFFFFFFu;
+        }
     }
     uint32_t lo = 0, hiv = 0xFFFFFFFEu;
-    for (int it = 0; it < 32; ++it) {
+    for (int it = 0; it < 32 && lo < hiv; ++it) {
         const uint32_t mid = lo + ((hiv - lo) >> 1);
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < 2 * CAPK / 64; ++u) c += v[u] <= mid ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        if (lo < hiv) { if (c >= K) hiv = mid; else lo = mid + 1; }
+        for (int u = 0; u < 2 * HC; ++u) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[u] <= mid));
+        if (c >= K) hiv = mid; else lo = mid + 1;
     }
     if (lane == 0) kth[row] = sortable_f32(lo);
 }

@@ -15,6 +15,7 @@
 // SEDNet.py:322,326). For mlp1 only max_N relu(GN(y)) is needed, and relu(affine) is monotone per channel,
 // so the epilogue keeps per-channel max/min over the tile instead of writing the [N,1024] tensor.
 #include "common.h"
+#include <type_traits>
 #include "split16.h"
 
 namespace {
@@ -310,38 +311,63 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
         if (ch + 1 < nchunk) step(ch + 1, xa1, 1);
     }
 
-    // ---- epilogue (pointwise_kernel's)
+    // ---- epilogue (pointwise_kernel's arithmetic and summation order). The element loop is instantiated for every flag
+    // combination and for "all 32 points of the wave's tile exist" (every tile but a cloud's last): no
+    // per-element flag tests, masks or 64-bit address arithmetic (the generic form was ~1900 instructions per wave, a third of
+    // the kernel at K = 256); a point row's address is a uniform base + one 32-bit lane offset.
     const int pw = p0 + wave * 32;
     unsigned vmask = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) vmask |= (pw + mfma_row(r, hi) < N ? 1u : 0u) << r;
+    const bool full = pw + 32 <= N;
+    auto tiles = [&](auto relu_c, auto store_c, auto stats_c, auto ext_c, auto full_c) {
+        constexpr bool RELU = decltype(relu_c)::value, STORE = decltype(store_c)::value, STATS = decltype(stats_c)::value,
+                       EXT = decltype(ext_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int o = o0 + 32 * t + li;
-        float add = bias ? bias[o] : 0.f;
-        if (cbias) add += cbias[(size_t)cloud * Coutp + o];
-        float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
+        for (int t = 0; t < TN; ++t) {
+            const int o = o0 + 32 * t + li;
+            float add = bias ? bias[o] : 0.f;
+            if (cbias) add += cbias[(size_t)cloud * Coutp + o];
+            float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
+            const unsigned loff = (unsigned)(4 * hi * ldy + o);          // lane part of the address: row 4 hi, channel o
+            const bool och = o < Cout;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[t][r] + add;
-            if (flags & F_RELU) v = fmaxf(v, 0.f);
-            const bool ok = (vmask >> r) & 1u;
-            if ((flags & F_STORE) && ok && o < Cout)
-                Y[((size_t)cloud * N + pw + mfma_row(r, hi)) * ldy + o] = v;
-            if (ok) { ps += v; pq = fmaf(v, v, pq); mx = fmaxf(mx, v); mn = fminf(mn, v); }
-        }
-        if (flags & F_STATS) {
-            double d1 = (double)ps, d2 = (double)pq;
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r] + add;
+                if (RELU) v = sed_vmax(v, 0.f);
+                const bool ok = FULL || ((vmask >> r) & 1u);
+                if (STORE && ok && och) {
+                    float* rowbase = Y + ((size_t)cloud * N + pw + ((r & 3) + 8 * (r >> 2))) * ldy;     // uniform
+                    rowbase[loff] = v;
+                }
+                if (ok) {
+                    if (STATS) { ps += v; pq = fmaf(v, v, pq); }
+                    if (EXT) { mx = sed_vmax(mx, v); mn = sed_vmin(mn, v); }
+                }
+            }
+            if (STATS) {
+                double d1 = (double)ps, d2 = (double)pq;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
-            if (lane == 0) { red[(wave * TN + t) * 2] = d1; red[(wave * TN + t) * 2 + 1] = d2; }
+                for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+                if (lane == 0) { red[(wave * TN + t) * 2] = d1; red[(wave * TN + t) * 2 + 1] = d2; }
+            }
+            if (EXT) {
+                mx = fmaxf(mx, xor32(mx));
+                mn = fminf(mn, xor32(mn));
+                if (hi == 0) { ext[(wave * BN + 32 * t + li) * 2] = mx; ext[(wave * BN + 32 * t + li) * 2 + 1] = mn; }
+            }
         }
-        if (flags & F_COLEXT) {
-            mx = fmaxf(mx, xor32(mx));
-            mn = fminf(mn, xor32(mn));
-            if (hi == 0) { ext[(wave * BN + 32 * t + li) * 2] = mx; ext[(wave * BN + 32 * t + li) * 2 + 1] = mn; }
-        }
-    }
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    auto with_full = [&](auto relu_c, auto store_c, auto stats_c, auto ext_c) {
+        if (full) tiles(relu_c, store_c, stats_c, ext_c, TT{});
+        else tiles(relu_c, store_c, stats_c, ext_c, FF{});
+    };
+    auto d3 = [&](auto a, auto b, auto c) { if (flags & F_COLEXT) with_full(a, b, c, TT{}); else with_full(a, b, c, FF{}); };
+    auto d2 = [&](auto a, auto b) { if (flags & F_STATS) d3(a, b, TT{}); else d3(a, b, FF{}); };
+    auto d1 = [&](auto a) { if (flags & F_STORE) d2(a, TT{}); else d2(a, FF{}); };
+    if (flags & F_RELU) d1(TT{}); else d1(FF{});
     if (flags & (F_STATS | F_COLEXT)) __syncthreads();
     if ((flags & F_STATS) && tid < TN * 2) {
         const int t = tid >> 1, which = tid & 1;

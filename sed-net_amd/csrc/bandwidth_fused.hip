@@ -19,6 +19,8 @@
 #include "split16.h"
 #include <type_traits>
 
+int sed_sel_chunks(int B, int N);                    // knn_fused.hip: key chunks of the second sweeps
+
 namespace {
 
 constexpr int BM = 8;             // minima kept per bucket in sweep 1
@@ -112,16 +114,18 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
         Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);
-        mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPK;
+        mylist = lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPK;
     }
 
     const int tstep = (PASS == 1 && N >= 4096) ? 2 : 1;
-    stage_load(0);
+    // few clouds per call: sweep 2 runs gridDim.z key chunks per query block (knn_fused.hip: sed_sel_chunks), one list pair each
+    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
+    stage_load(t0);
     stage_store(0);
     __syncthreads();
     int cur = 0;
-    for (int tile = 0; tile < ntiles; tile += tstep) {
-        if (tile + tstep < ntiles) stage_load(tile + tstep);
+    for (int tile = t0; tile < t1; tile += tstep) {
+        if (tile + tstep < t1) stage_load(tile + tstep);
         const float* xt = lds[cur];
         f32x16 s;
         if (F16) {
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         // (sweep 1 keeps ONE instantiation: with 128 bucket registers a second copy of the network makes the allocator spill)
         if (PASS == 1 || ragged) select(std::true_type{});
         else select(std::false_type{});
-        if (tile + tstep < ntiles) stage_store(cur ^ 1);
+        if (tile + tstep < t1) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -199,33 +203,55 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         }
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else if (qrow < N) {
-        counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
-        if (cnt > CAPK || cnt + __shfl_xor(cnt, 32, 64) < K) overflow[cloud] = 1;   // list overflow / T below the K-th value
+        counts[(((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi] = cnt;
+        if (cnt > CAPK) overflow[cloud] = 1;          // list overflow (T below the K-th value: counted by the finalize kernel)
     }
 }
 
-// one wave per query: exact K-th smallest of its candidates (<= 2 CAPK keys). grid ceil(rows / 4), block 256.
-// Counting is ballot + popcount (uniform, no cross-lane shuffles); the loads are unconditional from clamped positions and
-// skipped uniformly for the 64-entry chunks beyond a list's count, so all of a row's loads are in flight together.
+// one wave per query: exact K-th smallest of its candidates (<= 2 CAPK keys in the union of its S list pairs; S = key chunks of
+// sweep 2). grid ceil(rows / 4), block 256. Counting is ballot + popcount (uniform, no cross-lane shuffles); the loads are
+// unconditional from clamped positions and skipped uniformly for 64-entry chunks beyond the union's size, so all of a row's
+// loads are in flight together. A union of fewer than K candidates (the sampled threshold of sweep 1 fell below the K-th
+// value) or of more than the 2 CAPK register slots raises the cloud's flag.
 __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __restrict__ lists,
-                                                              const int* __restrict__ counts, int K, size_t rows,
-                                                              float* __restrict__ kth) {
+                                                              const int* __restrict__ counts, int K, size_t rows, int N,
+                                                              int S, float* __restrict__ kth, int* __restrict__ overflow) {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const int c0 = __builtin_amdgcn_readfirstlane(min(counts[row * 2], CAPK));
-    const int c1 = __builtin_amdgcn_readfirstlane(min(counts[row * 2 + 1], CAPK));
-    const uint32_t* l0 = lists + row * 2 * CAPK;
-    constexpr int HC = CAPK / 64;                     // 64-entry chunks per half-list
-    uint32_t v[2 * HC];
+    constexpr int MAXS = 4;
+    int ca[MAXS], cb[MAXS], tot = 0;
 #pragma unroll
-    for (int u = 0; u < 2 * HC; ++u) {
-        const int cu = u < HC ? c0 : c1;              // count of the half-list this chunk belongs to
-        const int i = lane + 64 * (u % HC);           // position inside the half-list
+    for (int p = 0; p < MAXS; ++p) {
+        ca[p] = p < S ? __builtin_amdgcn_readfirstlane(min(counts[(row * S + p) * 2], CAPK)) : 0;
+        cb[p] = p < S ? __builtin_amdgcn_readfirstlane(min(counts[(row * S + p) * 2 + 1], CAPK)) : 0;
+        tot += ca[p] + cb[p];
+    }
+    if (tot < K || tot > 2 * CAPK) {
+        if (lane == 0) overflow[row / (size_t)N] = 1;
+        tot = tot > 2 * CAPK ? 2 * CAPK : tot;
+    }
+    const uint32_t* base = lists + row * S * 2 * CAPK;
+    constexpr int NV = 2 * CAPK / 64;
+    uint32_t v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int e = lane + 64 * u;                  // entry of the union
         v[u] = 0xFFFFFFFFu;
-        if (64 * (u % HC) < cu) {
-            const uint32_t x = l0[(u < HC ? 0 : CAPK) + (i < cu ? i : 0)];
-            v[u] = i < cu ? x : 0xFFFFFFFFu;
+        if (64 * u < tot) {
+            const bool ok = e < tot;
+            int rel = ok ? e : 0, off = 0;
+#pragma unroll
+            for (int p = 0; p < MAXS; ++p) {
+                const int n = ca[p] + cb[p];
+                if (p < S - 1 && rel >= n && off == 2 * CAPK * p) { rel -= n; off = 2 * CAPK * (p + 1); }
+            }
+            const int p = off / (2 * CAPK);
+            int ap = ca[0];
+#pragma unroll
+            for (int pp = 1; pp < MAXS; ++pp) ap = p == pp ? ca[pp] : ap;
+            const uint32_t x = base[off + (rel < ap ? rel : CAPK + rel - ap)];
+            v[u] = ok ? x : 0xFFFFFFFFu;
         }
     }
     uint32_t lo = 0, hiv = 0xFFFFFFFEu;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __
         const uint32_t mid = lo + ((hiv - lo) >> 1);
         int c = 0;
 #pragma unroll
-        for (int u = 0; u < 2 * HC; ++u) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[u] <= mid));
+        for (int u = 0; u < NV; ++u) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[u] <= mid));
         if (c >= K) hiv = mid; else lo = mid + 1;
     }
     if (lane == 0) kth[row] = sortable_f32(lo);
@@ -245,8 +271,9 @@ KWs kcarve(void* ws, int B, int N) {
     KWs w;
     w.T = (uint32_t*)ws;
     w.counts = (int*)(w.T + bn);
-    w.lists = (uint32_t*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
-    w.inv = (float*)(w.lists + bn * 2 * CAPK);
+    const size_t S = (size_t)sed_sel_chunks(B, N);
+    w.lists = (uint32_t*)(((uintptr_t)(w.counts + 2 * S * bn) + 15) & ~(uintptr_t)15);
+    w.inv = (float*)(w.lists + bn * 2 * S * CAPK);
     w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
     return w;
 }
@@ -262,7 +289,8 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
         X = (const float*)w.img;
     }
     ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
-    ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
+    ms_kth_sweep_kernel<NT, 2, F16><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
 }
 
 }  // namespace
@@ -272,7 +300,8 @@ extern "C" int sed_ms_kth_fused_max_k(int N) { return N >= 4096 ? KMAX_SAMPLED :
 
 extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
-    return bn * sizeof(uint32_t) + bn * 2 * sizeof(int) + bn * 2 * CAPK * sizeof(uint32_t) + 256 +
+    const size_t S = (size_t)sed_sel_chunks(B, N);
+    return bn * sizeof(uint32_t) + bn * 2 * S * sizeof(int) + bn * 2 * S * CAPK * sizeof(uint32_t) + 256 +
            bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 256;
 }
 
@@ -296,7 +325,8 @@ extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, 
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
-    ms_kth_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, K, rows, kth);
+    ms_kth_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, K, rows, N, sed_sel_chunks(B, N), kth,
+                                                                           overflow);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -17,6 +17,15 @@
 #include "split16.h"
 #include <type_traits>
 
+constexpr int SEL_MAXCHUNK_ = 4;
+// key chunks of the second sweeps: 1 from ~4 clouds per call on; results do not depend on it
+int sed_sel_chunks(int B, int N) {
+    const long wg = (long)B * ((N + 127) / 128);
+    long S = 320 / (wg > 0 ? wg : 1);
+    if (N < 2048) S = 1;
+    return (int)(S < 1 ? 1 : (S > SEL_MAXCHUNK_ ? SEL_MAXCHUNK_ : S));
+}
+
 namespace {
 
 constexpr int CAPL = 96;          // candidates per lane (two lanes per query)
@@ -115,10 +124,14 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
         Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);      // fewer than k bucket values: take everything
-        mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPL;
+        mylist = lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPL;
     }
+    // Few clouds per call: sweep 2 is split over gridDim.z key chunks (sed_sel_chunks: a cloud's 79 workgroups alone cannot
+    // fill 256 CUs); chunk z appends to its own pair of half-lists, the finalize kernel ranks the union. Sweep 1 is launched
+    // with one chunk.
+    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
 
-    stage_load(0);
+    stage_load(t0);
     stage_store(0);
     __syncthreads();
     int cur = 0;
@@ -127,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     // candidates and the selection stays exact. Only for k <= 32, where 2x the candidates (~2.5 k per query, half per
     // lane) stay far below the list capacity; larger k keep the full first sweep.
     const int tstep = (PASS == 1 && N >= 4096 && k <= 32) ? 2 : 1;
-    for (int tile = 0; tile < ntiles; tile += tstep) {
-        if (tile + tstep < ntiles) stage_load(tile + tstep);
+    for (int tile = t0; tile < t1; tile += tstep) {
+        if (tile + tstep < t1) stage_load(tile + tstep);
         const float* xt = lds[cur];
         f32x16 s;
         if (F16) {
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
         };
         if (ragged) select(std::true_type{});
         else select(std::false_type{});
-        if (tile + tstep < ntiles) stage_store(cur ^ 1);
+        if (tile + tstep < t1) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else {
         if (qrow < N) {
-            counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;
+            counts[(((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi] = cnt;
             if (cnt > CAPL) *overflow = 1;
         }
     }
@@ -244,8 +257,9 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     Cand* mylist = nullptr;
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qc];
-        mylist = lists + ((size_t)cloud * N + qc) * 2 * CAPL;       // one thread owns both halves
+        mylist = lists + (((size_t)cloud * N + qc) * gridDim.z + blockIdx.z) * 2 * CAPL;       // one thread owns both halves
     }
+    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
     auto stage = [&](int tile, int buf) {
         if (tid < 32) {
             int j = tile * 32 + tid;
@@ -258,14 +272,14 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
             ks[buf][tid][7] = ok ? 1.f : 0.f;
         }
     };
-    stage(0, 0);
+    stage(t0, 0);
     __syncthreads();
     // sweep 1 on every other key tile for small k on large clouds (see knn_sweep_kernel)
     const int tstep = (PASS == 1 && N >= 4096 && k <= 32) ? 2 : 1;
     int cur = 1;
-    for (int tile = 0; tile < ntiles; tile += tstep) {
+    for (int tile = t0; tile < t1; tile += tstep) {
         cur ^= 1;
-        if (tile + tstep < ntiles) stage(tile + tstep, cur ^ 1);
+        if (tile + tstep < t1) stage(tile + tstep, cur ^ 1);
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
             const float* kq = ks[cur][r];
@@ -300,8 +314,8 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
         }
         if (qi < N) Tbuf[(size_t)cloud * N + qi] = lo;
     } else if (qi < N) {
-        counts[((size_t)cloud * N + qi) * 2] = cnt < 2 * CAPL ? cnt : 2 * CAPL;
-        counts[((size_t)cloud * N + qi) * 2 + 1] = 0;
+        counts[(((size_t)cloud * N + qi) * gridDim.z + blockIdx.z) * 2] = cnt < 2 * CAPL ? cnt : 2 * CAPL;
+        counts[(((size_t)cloud * N + qi) * gridDim.z + blockIdx.z) * 2 + 1] = 0;
         if (cnt > 2 * CAPL) *overflow = 1;
     }
 }
@@ -311,30 +325,46 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
 // v_readlane: no LDS round trip per comparison (the LDS version spent its time in 60 dependent ds_read latencies per row).
 // rank = number of candidates that sort before mine by (key, index); ranks are distinct, the k smallest are written in order.
 constexpr int FIN_ROWS = 4;                        // rows per wave: all their loads are in flight before the first rank loop
+constexpr int SEL_MAXCHUNK = 4;                    // key chunks of sweep 2 at few clouds per call (sed_sel_chunks)
+// S = key chunks of sweep 2: a row owns S pairs of half-lists (pair p at ((row S + p) 2) CAPL), pair p holds a_p entries from
+// its start and b_p entries from its second half (the xyz-normal kernel packs everything into the first). The union has the
+// same members as the one-chunk lists (same threshold T), so the ranks -- hence the output -- do not depend on S; a union
+// beyond the 2 CAPL register slots raises the overflow flag like a full list does.
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restrict__ lists, const int* __restrict__ counts,
-                                                           int k, size_t rows, int* __restrict__ idx_out) {
+                                                           int k, size_t rows, int S, int* __restrict__ idx_out,
+                                                           int* __restrict__ overflow) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t row0 = ((size_t)blockIdx.x * 4 + wave) * FIN_ROWS;
     if (row0 >= rows) return;
     constexpr int NCH = (2 * CAPL + 63) / 64;
-    int c0[FIN_ROWS], C[FIN_ROWS];
+    int pa[FIN_ROWS][SEL_MAXCHUNK], pb[FIN_ROWS][SEL_MAXCHUNK], C[FIN_ROWS];
 #pragma unroll
     for (int q = 0; q < FIN_ROWS; ++q) {
         const size_t row = row0 + q < rows ? row0 + q : rows - 1;
-        int a = counts[row * 2], b = counts[row * 2 + 1];
-        a = a < CAPL * 2 ? a : CAPL * 2;                // pn kernel packs everything into the first half-list pair
-        b = b < CAPL ? b : CAPL;
-        if (b > 0 && a > CAPL) a = CAPL;
-        c0[q] = a;
-        C[q] = row0 + q < rows ? a + b : 0;
+        int tot = 0;
+#pragma unroll
+        for (int p = 0; p < SEL_MAXCHUNK; ++p) {
+            int a = 0, b = 0;
+            if (p < S) {
+                a = counts[(row * S + p) * 2];
+                b = counts[(row * S + p) * 2 + 1];
+                a = a < CAPL * 2 ? a : CAPL * 2;        // pn kernel packs everything into the first half-list pair
+                b = b < CAPL ? b : CAPL;
+                if (b > 0 && a > CAPL) a = CAPL;
+            }
+            pa[q][p] = __builtin_amdgcn_readfirstlane(a);
+            pb[q][p] = __builtin_amdgcn_readfirstlane(b);
+            tot += pa[q][p] + pb[q][p];
+        }
+        if (tot > 2 * CAPL) { tot = 2 * CAPL; if (lane == 0 && row0 + q < rows) *overflow = 1; }
+        C[q] = row0 + q < rows ? tot : 0;
     }
     uint32_t key[FIN_ROWS][NCH];                        // (key, index) compared as ONE 64-bit number: key in the high word
     int idx[FIN_ROWS][NCH];
 #pragma unroll
     for (int q = 0; q < FIN_ROWS; ++q) {
         const size_t row = row0 + q < rows ? row0 + q : rows - 1;
-        const Cand* l0 = lists + row * 2 * CAPL;
-        const Cand* l1 = l0 + CAPL;
+        const Cand* base = lists + row * S * 2 * CAPL;
         const int Cu = __builtin_amdgcn_readfirstlane(C[q]);
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
@@ -344,8 +374,17 @@ __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restric
             key[q][t] = 0xFFFFFFFFu; idx[q][t] = 0x7FFFFFFF;
             if (64 * t < Cu) {
                 const bool ok = e < Cu;
-                const int ec = ok ? e : 0;
-                const Cand c = ec < c0[q] ? l0[ec] : l1[ec - c0[q]];
+                int rel = ok ? e : 0, off = 0;          // entry `rel` of the union -> position in its pair
+#pragma unroll
+                for (int p = 0; p < SEL_MAXCHUNK; ++p) {
+                    const int n = pa[q][p] + pb[q][p];
+                    if (p < S - 1 && rel >= n && off == 2 * CAPL * p) { rel -= n; off = 2 * CAPL * (p + 1); }
+                }
+                const int p = off / (2 * CAPL);
+                int ap = pa[q][0];
+#pragma unroll
+                for (int pp = 1; pp < SEL_MAXCHUNK; ++pp) ap = p == pp ? pa[q][pp] : ap;
+                const Cand c = base[off + (rel < ap ? rel : CAPL + rel - ap)];
                 key[q][t] = ok ? c.key : 0xFFFFFFFFu;
                 idx[q][t] = ok ? c.idx : 0x7FFFFFFF;
             }
@@ -390,8 +429,9 @@ int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 
 
 extern "C" size_t sed_knn_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
-    return bn * sizeof(float) /*xx*/ + bn * sizeof(uint32_t) /*T*/ + bn * 2 * sizeof(int) /*counts*/ +
-           bn * 2 * CAPL * sizeof(Cand) + 256 +
+    const size_t S = (size_t)sed_sel_chunks(B, N);
+    return bn * sizeof(float) /*xx*/ + bn * sizeof(uint32_t) /*T*/ + bn * 2 * S * sizeof(int) /*counts*/ +
+           bn * 2 * S * CAPL * sizeof(Cand) + 256 +
            bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image, d <= 128*/ + 256;
 }
 extern "C" int sed_knn_fused_max_k(void) { return 85; }
@@ -413,8 +453,9 @@ Ws carve(void* ws, int B, int N) {
     w.xx = (float*)ws;
     w.T = (uint32_t*)(w.xx + bn);
     w.counts = (int*)(w.T + bn);
-    w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * bn) + 15) & ~(uintptr_t)15);
-    w.inv = (float*)(((uintptr_t)(w.lists + bn * 2 * CAPL) + 15) & ~(uintptr_t)15);
+    const size_t S = (size_t)sed_sel_chunks(B, N);
+    w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * S * bn) + 15) & ~(uintptr_t)15);
+    w.inv = (float*)(((uintptr_t)(w.lists + bn * 2 * S * CAPL) + 15) & ~(uintptr_t)15);
     w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
     return w;
 }
@@ -433,12 +474,13 @@ void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* ov
         split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
         X = (const float*)w.img;
     }
+    const dim3 grid2(grid.x, grid.y, sed_sel_chunks((int)grid.y, N));        // sweep 2: key chunks at few clouds per call
     if (far) {
         knn_sweep_kernel<NT, M, 1, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
-        knn_sweep_kernel<NT, M, 2, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        knn_sweep_kernel<NT, M, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
     } else {
         knn_sweep_kernel<NT, M, 1, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
-        knn_sweep_kernel<NT, M, 2, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        knn_sweep_kernel<NT, M, 2, F16, false><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
     }
 }
 template <int NT>
@@ -491,7 +533,8 @@ static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int
     }
     if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();
-    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows, idx);
+    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows,
+                                                                                                  sed_sel_chunks(B, N), idx, overflow);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -505,27 +548,29 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
     hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid((N + 255) / 256, B);
+    const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
     switch (pick_M(k)) {
         case 1:
             knn_pn_sweep_kernel<1, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-            knn_pn_sweep_kernel<1, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<1, 2><<<grid2, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
             break;
         case 2:
             knn_pn_sweep_kernel<2, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-            knn_pn_sweep_kernel<2, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<2, 2><<<grid2, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
             break;
         case 3:                                                // k = 64, the reference script's default (round 2)
             knn_pn_sweep_kernel<3, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-            knn_pn_sweep_kernel<3, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<3, 2><<<grid2, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
             break;
         default:
             knn_pn_sweep_kernel<4, 1><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
-            knn_pn_sweep_kernel<4, 2><<<grid, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
+            knn_pn_sweep_kernel<4, 2><<<grid2, 256, 0, stream>>>(x6, N, k, W, w.T, w.lists, w.counts, overflow);
             break;
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
-    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, rows, idx);
+    knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, rows,
+                                                                                                  sed_sel_chunks(B, N), idx, overflow);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

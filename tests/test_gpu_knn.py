@@ -154,3 +154,29 @@ def test_graph_feature_surface_matches_reference(T, golden):
     b = get_graph_feature(x6, 20, 20, idx=idx)
     assert T.equal(a, b) and tuple(a.shape) == (1, 12, 512, 20)
     np.testing.assert_array_equal(a[0, 6:, :, 0].cpu().numpy(), g["x_a"][0])          # second half = the centre point
+
+
+def test_key_chunked_second_sweeps_do_not_change_results(T):
+    """Few clouds per call: the second sweeps of all three selection stages run 2-4 key chunks per query block (a cloud's 79
+    workgroups cannot fill 256 CUs) and the finalize kernels rank the union of the chunks' lists. Same threshold, same
+    candidates: the indices / K-th distances of a cloud are bit-identical whether it is processed alone (4 chunks), with one
+    other cloud (2 chunks) or in a batch of five (1 chunk) -- at N = 10 000 and on a ragged N with duplicated points."""
+    from sednet_hip import ops, synth
+    for N in (10000, 4099):
+        g = T.Generator().manual_seed(N)
+        F = T.randn(5, N, 64, generator=g)
+        F[:, 17] = F[:, 3]                                       # duplicates: ties resolved by the lower index in every form
+        F = F.cuda()
+        x6 = T.from_numpy(synth.batch_clouds(5, N, seed0=77)[0]).cuda()
+        X = T.nn.functional.normalize(T.randn(5, N, 128, generator=g), dim=2).cuda()
+        for k in (20, 64):
+            full = ops.knn_features(F, k, 64)
+            np.testing.assert_array_equal(ops.knn_features(F[:1].contiguous(), k, 64).cpu().numpy(), full[:1].cpu().numpy())
+            np.testing.assert_array_equal(ops.knn_features(F[1:3].contiguous(), k, 64).cpu().numpy(), full[1:3].cpu().numpy())
+            fullp = ops.knn_points_normals(x6, k, 1.0)
+            np.testing.assert_array_equal(ops.knn_points_normals(x6[:1].contiguous(), k, 1.0).cpu().numpy(), fullp[:1].cpu().numpy())
+            np.testing.assert_array_equal(ops.knn_points_normals(x6[3:5].contiguous(), k, 1.0).cpu().numpy(), fullp[3:5].cpu().numpy())
+        for K in (150, 180):
+            bw = ops.ms_bandwidth(X, K, 0.003)
+            assert T.equal(ops.ms_bandwidth(X[:1].contiguous(), K, 0.003), bw[:1])
+            assert T.equal(ops.ms_bandwidth(X[2:4].contiguous(), K, 0.003), bw[2:4])

@@ -40,7 +40,7 @@ __host__ __device__ inline int sweep1_rank(int K, bool sampled) {
 }
 
 // F16 (d = 64 / 128): split-fp16 dot products on the pre-split row image (split16.h), like knn_fused.hip.
-template <int NT, int PASS, bool F16>
+template <int NT, int PASS, bool F16, bool CHUNK = false>      // CHUNK: see knn_sweep_kernel
 __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, const float* __restrict__ inv,
                                                               int N, int K,
                                                               uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ lists,
@@ -114,12 +114,14 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
         Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);
-        mylist = lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPK;
+        mylist = CHUNK ? lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPK
+                       : lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPK;
     }
 
     const int tstep = (PASS == 1 && N >= 4096) ? 2 : 1;
     // few clouds per call: sweep 2 runs gridDim.z key chunks per query block (knn_fused.hip: sed_sel_chunks), one list pair each
-    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
+    const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
+    const int t0 = CHUNK ? (int)(ntiles * blockIdx.z) >> zsh : 0, t1 = CHUNK ? (int)(ntiles * (blockIdx.z + 1)) >> zsh : ntiles;
     stage_load(t0);
     stage_store(0);
     __syncthreads();
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         }
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else if (qrow < N) {
-        counts[(((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi] = cnt;
+        counts[CHUNK ? (((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi : ((size_t)cloud * N + qrow) * 2 + hi] = cnt;
         if (cnt > CAPK) overflow[cloud] = 1;          // list overflow (T below the K-th value: counted by the finalize kernel)
     }
 }
@@ -290,7 +292,8 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
     }
     ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
-    ms_kth_sweep_kernel<NT, 2, F16><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
 }
 
 }  // namespace

@@ -17,13 +17,12 @@
 #include "split16.h"
 #include <type_traits>
 
-constexpr int SEL_MAXCHUNK_ = 4;
 // key chunks of the second sweeps: 1 from ~4 clouds per call on; results do not depend on it
 int sed_sel_chunks(int B, int N) {
     const long wg = (long)B * ((N + 127) / 128);
     long S = 320 / (wg > 0 ? wg : 1);
     if (N < 2048) S = 1;
-    return (int)(S < 1 ? 1 : (S > SEL_MAXCHUNK_ ? SEL_MAXCHUNK_ : S));
+    return S >= 4 ? 4 : (S >= 2 ? 2 : 1);             // a power of two <= SEL_MAXCHUNK (the kernels split the tiles by shifts)
 }
 
 namespace {
@@ -37,7 +36,10 @@ struct Cand { uint32_t key; int idx; };
 // same bytes per row as the fp32 row; inv = the rows' 2^-e); otherwise exact fp32 MFMA chains on X itself.
 // FAR: the k LARGEST distances (smooth_normal_matrix.py:33-40). Tiles are processed by a lambda instantiated twice: only the
 // cloud's last, partly filled tile pays for the padding tests.
-template <int NT, int M, int PASS, bool F16, bool FAR>
+// CHUNK (sweep 2 at few clouds per call): gridDim.z key chunks per query block. A template parameter because the one-chunk
+// instantiation needs 126 registers (4 waves per SIMD) and the chunked one 154 (3 waves: 10 % slower per wave, irrelevant
+// when the chip is not full anyway).
+template <int NT, int M, int PASS, bool F16, bool FAR, bool CHUNK = false>
 __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restrict__ X, const float* __restrict__ xx,
                                                            const float* __restrict__ inv,
                                                            int N, int k, uint32_t* __restrict__ Tbuf,
@@ -124,12 +126,14 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qrow_c];
         Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);      // fewer than k bucket values: take everything
-        mylist = lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPL;
+        mylist = CHUNK ? lists + ((((size_t)cloud * N + qrow_c) * gridDim.z + blockIdx.z) * 2 + hi) * CAPL
+                       : lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPL;
     }
     // Few clouds per call: sweep 2 is split over gridDim.z key chunks (sed_sel_chunks: a cloud's 79 workgroups alone cannot
     // fill 256 CUs); chunk z appends to its own pair of half-lists, the finalize kernel ranks the union. Sweep 1 is launched
     // with one chunk.
-    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
+    const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
+    const int t0 = CHUNK ? (int)(ntiles * blockIdx.z) >> zsh : 0, t1 = CHUNK ? (int)(ntiles * (blockIdx.z + 1)) >> zsh : ntiles;
 
     stage_load(t0);
     stage_store(0);
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
         if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = lo;
     } else {
         if (qrow < N) {
-            counts[(((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi] = cnt;
+            counts[CHUNK ? (((size_t)cloud * N + qrow) * gridDim.z + blockIdx.z) * 2 + hi : ((size_t)cloud * N + qrow) * 2 + hi] = cnt;
             if (cnt > CAPL) *overflow = 1;
         }
     }
@@ -259,7 +263,8 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
         T = Tbuf[(size_t)cloud * N + qc];
         mylist = lists + (((size_t)cloud * N + qc) * gridDim.z + blockIdx.z) * 2 * CAPL;       // one thread owns both halves
     }
-    const int t0 = (int)((long)ntiles * blockIdx.z / gridDim.z), t1 = (int)((long)ntiles * (blockIdx.z + 1) / gridDim.z);
+    const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
+    const int t0 = (int)(ntiles * blockIdx.z) >> zsh, t1 = (int)(ntiles * (blockIdx.z + 1)) >> zsh;
     auto stage = [&](int tile, int buf) {
         if (tid < 32) {
             int j = tile * 32 + tid;
@@ -477,10 +482,16 @@ void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* ov
     const dim3 grid2(grid.x, grid.y, sed_sel_chunks((int)grid.y, N));        // sweep 2: key chunks at few clouds per call
     if (far) {
         knn_sweep_kernel<NT, M, 1, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
-        knn_sweep_kernel<NT, M, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        if (grid2.z > 1)
+            knn_sweep_kernel<NT, M, 2, F16, true, true><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        else
+            knn_sweep_kernel<NT, M, 2, F16, true><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
     } else {
         knn_sweep_kernel<NT, M, 1, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
-        knn_sweep_kernel<NT, M, 2, F16, false><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        if (grid2.z > 1)
+            knn_sweep_kernel<NT, M, 2, F16, false, true><<<grid2, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
+        else
+            knn_sweep_kernel<NT, M, 2, F16, false><<<grid, 256, 0, s>>>(X, w.xx, w.inv, N, k, w.T, w.lists, w.counts, overflow);
     }
 }
 template <int NT>

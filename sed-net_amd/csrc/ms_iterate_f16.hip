@@ -1160,6 +1160,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
                 const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
                 plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
             } else {
+                // (one v_dot2c_f32_f16 against (1, 1) per pair instead of two conversions + two adds was tried in the f16r kernel: 361 vs
+                // 287 ms -- the dot instruction is slow beside the MFMAs and the allocator moved a reload into the loop)
                 rsum += (float)h[0] + (float)h[1];
             }
         };

@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ S, const float* __restrict__ y, int ldy,
                                                            const float* __restrict__ ak, int N, int C, int G) {
     const int cloud = blockIdx.y;
-    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int c4n = C / 4;
-    if (i4 >= (size_t)N * c4n) return;
-    const int row = (int)(i4 / c4n), c = (int)(i4 % c4n) * 4;
+    const unsigned i4 = blockIdx.x * 256u + threadIdx.x;              // N * C / 4 < 2^32: 32-bit index arithmetic
+    const unsigned c4n = (unsigned)C / 4;
+    if (i4 >= (unsigned)N * c4n) return;
+    const int row = (int)(i4 / c4n), c = (int)(i4 - (unsigned)row * c4n) * 4;
     const int g = c / (C / G);
     const float a = ak[((size_t)cloud * G + g) * 2], kp = ak[((size_t)cloud * G + g) * 2 + 1];
     const size_t o = (size_t)cloud * N + row;

@@ -164,6 +164,9 @@ int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, co
  * -> ysel [B,N,Cout] (max_k y where gamma >= 0 else min_k y), stats [B][G][2] = (mean, rstd).
  * src/PointNet.py:150-171 + src/SEDNet.py:37-45 + :82 */
 size_t sed_edgeconv_partials_bytes(int B, int N, int Cout);
+/* Products of the inference forward of the 64-channel layers (sed_edgeconv_fwd_f32): on = 1 (default) three-way bf16 splits of
+ * both operands on the bf16 matrix pipe (six MFMAs per 16 channels, fp32-equivalent), 0 = fp32-input MFMA chains. */
+int sed_edgeconv_set_split(int on);
 int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                          const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
                          void* partials, size_t partials_bytes, sed_stream_t stream);

@@ -29,7 +29,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BF16 (training, BASELINE configs[4]; CH = 32 only): the difference x_j - x_i is still formed in fp32, then rounded to
 // bf16 (nearest even) like the weights; products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 / fp64 statistics.
 // LDS holds the two weight halves transposed, [64 out channels][64 in channels] bf16 with a 144-byte row stride.
-template <int CH, bool TRAIN, bool BF16 = false>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
+// X3 (inference, CH = 32; round 2): both operands as three-way bf16 splits, six bf16 MFMAs per 16 channels -- the scheme of
+// pointwise_split_kernel (fp32-equivalent: dropped terms <= 2^-25 of |x||w| per product, where the fp32 chain it replaces rounds
+// 64 times) -- 1536 instead of 4096 matrix cycles per neighbour and wave. LDS: three planes of each transposed weight half.
+template <int CH, bool TRAIN, bool BF16 = false, bool X3 = false>   // channels per lane-half; C = 2 * CH   (CH = 3: xyz|normal input, CH = 32: 64-d features)
 __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restrict__ x, int ldx,
                                                           const int* __restrict__ idx, int k,
                                                           const float* __restrict__ W1t,
@@ -41,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w1 = smem;                // [C][64]
     float* w2 = smem + C * 64;       // [C][64]
-    double* red = (double*)(smem + 2 * C * 64);   // [4 waves][2 tiles][2]
+    // [4 waves][2 tiles][2], behind the weights (X3: three bf16 planes of both halves, 144-byte rows)
+    double* red = (double*)((uint8_t*)smem + (X3 ? (size_t)2 * 3 * 64 * (C + 8) * sizeof(__bf16) : (size_t)2 * C * 64 * sizeof(float)));
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     // XCD-aware block mapping (speed only): consecutive workgroup ids are dealt round-robin to the 8 XCDs; remapping
@@ -53,11 +57,25 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     const int cloud = wgid / nbx, bxi = wgid - cloud * nbx;
     const int slab = blockIdx.z, o0 = slab * 64;
     constexpr int LDWB = C + 8;                  // bf16 image row stride in halves (144 B for C = 64)
-    __bf16* w1b = (__bf16*)smem;                 // [64][LDWB]
-    __bf16* w2b = w1b + 64 * LDWB;
+    constexpr int WPL = 64 * LDWB;               // one bf16 plane of one weight half
+    __bf16* w1b = (__bf16*)smem;                 // [64][LDWB]  (X3: [3][64][LDWB])
+    __bf16* w2b = w1b + (X3 ? 3 : 1) * WPL;
     for (int i = tid; i < C * 64; i += 256) {
         const int c = i >> 6, o = i & 63;
-        if (BF16) {
+        if (X3) {
+            const float* src[2] = {W1t, W2t};
+            __bf16* dst[2] = {w1b, w2b};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = src[h][(size_t)c * Cout + o0 + o];
+                const __bf16 p1 = (__bf16)v;
+                const float r1 = v - (float)p1;
+                const __bf16 p2 = (__bf16)r1;
+                dst[h][o * LDWB + c] = p1;
+                dst[h][WPL + o * LDWB + c] = p2;
+                dst[h][2 * WPL + o * LDWB + c] = (__bf16)(r1 - (float)p2);
+            }
+        } else if (BF16) {
             w1b[o * LDWB + c] = (__bf16)W1t[(size_t)c * Cout + o0 + o];
             w2b[o * LDWB + c] = (__bf16)W2t[(size_t)c * Cout + o0 + o];
         } else {
@@ -68,7 +86,31 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     __syncthreads();
     // bf16 product of this lane's CH channels (k-step s8 = channels hi * CH + 8 s8 .. + 8) with a transposed weight image
     auto mma_bf16 = [&](const float (&v)[CH], const __bf16* wb, f32x16 (&acc)[2]) {
-        if constexpr (BF16) {
+        if constexpr (X3) {
+#pragma unroll
+            for (int s8 = 0; s8 < CH / 8; ++s8) {
+                bf16x8 a1, a2, a3;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float x0 = v[8 * s8 + i];
+                    const __bf16 p1 = (__bf16)x0;
+                    const float r1 = x0 - (float)p1;
+                    const __bf16 p2 = (__bf16)r1;
+                    a1[i] = p1; a2[i] = p2; a3[i] = (__bf16)(r1 - (float)p2);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const __bf16* wp = wb + (32 * t + li) * LDWB + hi * CH + 8 * s8;
+                    const bf16x8 b1 = *(const bf16x8*)wp, b2 = *(const bf16x8*)(wp + WPL), b3 = *(const bf16x8*)(wp + 2 * WPL);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);      // smallest terms first
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+                }
+            }
+        } else if constexpr (BF16) {
 #pragma unroll
             for (int s8 = 0; s8 < CH / 8; ++s8) {
                 bf16x8 a;
@@ -110,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) base[t][r] = 0.f;
-    if (BF16) {
+    if (BF16 || X3) {
         mma_bf16(xc, w2b, base);
     } else {
 #pragma unroll
@@ -141,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
         for (int s = 0; s < CH; ++s) diff[s] = nxt[s] - xc[s];         // feature - x   (PointNet.py:170)
         if (j + 1 < k) load_row(ib[j + 1], nxt);
         f32x16 acc[2] = {base[0], base[1]};
-        if (BF16) {
+        if (BF16 || X3) {
             mma_bf16(diff, w1b, acc);
         } else {
 #pragma unroll
@@ -224,6 +266,13 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, in
 
 }  // namespace
 
+// inference products of the 64-channel layers: 1 = three-way bf16 splits on the bf16 matrix pipe (default), 0 = fp32-input MFMA
+static int g_edgeconv_x3 = 1;
+extern "C" int sed_edgeconv_set_split(int on) {
+    g_edgeconv_x3 = on ? 1 : 0;
+    return SED_OK;
+}
+
 extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
     return (size_t)B * ((N + 127) / 128) * (Cout / 32) * 2 * sizeof(double);
 }
@@ -254,7 +303,11 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
             edgeconv_kernel<32, true, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
         else if (jsel)
             edgeconv_kernel<32, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
-        else
+        else if (g_edgeconv_x3) {
+            const size_t sm3 = (size_t)2 * 3 * 64 * (64 + 8) * sizeof(__bf16) + 16 * sizeof(double) + 64;
+            edgeconv_kernel<32, false, false, true><<<grid, block, sm3, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N,
+                                                                                  nullptr);
+        } else
             edgeconv_kernel<32, false><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, nullptr);
     } else {
         return SED_EUNSUPPORTED;

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_nms_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sed_edgeconv_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_edgeconv_set_split": (c_int, [c_int]),
     "sed_edgeconv_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P, P,
                                      P, c_size_t, P]),
     "sed_edgeconv_fwd_train_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,

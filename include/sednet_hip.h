@@ -81,6 +81,9 @@ int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, 
  * the materialised path for that cloud.
  * src/mean_shift.py:115-137 (compute_bandwidth: dist = 2 - 2 X X^T, topk(K)). */
 int sed_ms_kth_fused_max_k(int N);
+/* first-sweep sampling of clouds of >= 8192 points: 4 = every fourth key tile (default), 2 = every other one (results identical:
+ * the second sweep verifies the threshold and flags the cloud otherwise) */
+int sed_ms_kth_set_sampling(int stride);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
 int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
                          int* overflow, sed_stream_t stream);

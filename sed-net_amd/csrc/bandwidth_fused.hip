@@ -23,7 +23,7 @@ int sed_sel_chunks(int B, int N);                    // knn_fused.hip: key chunk
 
 namespace {
 
-constexpr int BM = 8;             // minima kept per bucket in sweep 1
+constexpr int BM_FULL = 8;        // minima kept per bucket in sweep 1 (4 with quarter sampling)
 constexpr int CAPK = 256;         // candidates per lane (two lanes per query)
 constexpr int KMAX = 160;         // every key visited in sweep 1 (N < 4096)
 constexpr int KMAX_SAMPLED = 224; // sweep 1 on every other key tile (N >= 4096); beyond, the 8-deep buckets saturate
@@ -34,13 +34,20 @@ constexpr int KMAX_SAMPLED = 224; // sweep 1 on every other key tile (N >= 4096)
 // the sampled half is ~ Binomial(K, 1/2), so rank K / 2 + 3 sqrt(K) + 2 (six standard deviations above the mean) puts T
 // above the true K-th except with probability ~1e-9 per row -- or for rows whose nearest keys crowd into the unvisited
 // tiles. Sweep 2 counts what it finds: a row with fewer than K candidates raises the overflow flag (materialised path).
-__host__ __device__ inline int sweep1_rank(int K, bool sampled) {
+// Quarter sampling (clouds of >= 8192 points; end of round 2): every fourth key tile, rank K / 4 + 6 sqrt(3 K / 16) + 2 (six
+// standard deviations of Binomial(K, 1/4) above its mean) among 32 x 4 bucket values: half the first sweep's tiles and half its
+// bucket network, ~4 x rank = 280 candidates at K = 150 instead of 300. The same verification: sweep 2 counts what it finds.
+// Only for K <= 160: at the guard retries' K = 180 / 216 the rank (82 / 94 of 128 kept values) saturates the 4-deep buckets, the
+// threshold loosens and the candidate lists overflow (measured: 13 -> 35-40 ms through the fall-back).
+__host__ __device__ inline int sweep1_rank(int K, int samp) {
+    if (samp == 4) return (int)(0.25f * (float)K + 6.0f * sqrtf(0.1875f * (float)K)) + 2;
+    const bool sampled = samp == 2;
     if (!sampled || K <= KMAX) return K;
     return (int)(0.5f * (float)K + 3.0f * sqrtf((float)K)) + 2;
 }
 
 // F16 (d = 64 / 128): split-fp16 dot products on the pre-split row image (split16.h), like knn_fused.hip.
-template <int NT, int PASS, bool F16, bool CHUNK = false>      // CHUNK: see knn_sweep_kernel
+template <int NT, int PASS, bool F16, bool CHUNK = false, int SAMP = 2>      // CHUNK: see knn_sweep_kernel; SAMP: sweep-1 tile stride
 __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, const float* __restrict__ inv,
                                                               int N, int K,
                                                               uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ lists,
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     };
 
     // bucket minima as floats, float prefilter in sweep 2: see knn_fused.hip
+    constexpr int BM = SAMP == 4 ? 4 : BM_FULL;     // minima kept per bucket
     float bm[PASS == 1 ? BM : 1][16];
     if (PASS == 1) {
 #pragma unroll
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
                        : lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPK;
     }
 
-    const int tstep = (PASS == 1 && N >= 4096) ? 2 : 1;
+    const int tstep = (PASS == 1 && N >= 4096) ? SAMP : 1;
     // few clouds per call: sweep 2 runs gridDim.z key chunks per query block (knn_fused.hip: sed_sel_chunks), one list pair each
     const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
     const int t0 = CHUNK ? (int)(ntiles * blockIdx.z) >> zsh : 0, t1 = CHUNK ? (int)(ntiles * (blockIdx.z + 1)) >> zsh : ntiles;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         for (int i = 0; i < BM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) bk[i][r] = bm[i][r] >= 3.0e38f ? 0xFFFFFFFFu : f32_sortable(bm[i][r]);
-        const int Ks = sweep1_rank(K, tstep == 2);
+        const int Ks = sweep1_rank(K, tstep);
         uint32_t lo = 0, hiv = 0xFFFFFFFFu;
         for (int it = 0; it < 32; ++it) {
             const uint32_t mid = lo + ((hiv - lo) >> 1);
@@ -280,6 +288,8 @@ KWs kcarve(void* ws, int B, int N) {
     return w;
 }
 
+int g_kth_quarter = 1;            // sweep 1 on every fourth key tile for N >= 8192 (sed_ms_kth_set_sampling)
+
 template <int NT>
 void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, hipStream_t s) {
     const dim3 grid((N + 127) / 128, B);
@@ -290,13 +300,23 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
         split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
         X = (const float*)w.img;
     }
-    ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    if (N >= 8192 && K <= KMAX && g_kth_quarter)      // (larger K: 128 bucket values saturate, T loosens, the lists overflow)
+        ms_kth_sweep_kernel<NT, 1, F16, false, 4><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    else
+        ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
     if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
 }
 
 }  // namespace
+
+// sweep-1 sampling of large clouds: 4 = every fourth key tile (default), 2 = every other one
+extern "C" int sed_ms_kth_set_sampling(int stride) {
+    if (stride != 2 && stride != 4) return SED_EINVAL;
+    g_kth_quarter = stride == 4;
+    return SED_OK;
+}
 
 // largest K the fused path takes for clouds of N points
 extern "C" int sed_ms_kth_fused_max_k(int N) { return N >= 4096 ? KMAX_SAMPLED : KMAX; }

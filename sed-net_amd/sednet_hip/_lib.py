@@ -34,6 +34,7 @@ SIGNATURES = {
     "sed_ms_bandwidth_finalize_f32": (c_int, [c_int, c_int, c_float, P, P, P]),
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_kth_fused_max_k": (c_int, [c_int]),
+    "sed_ms_kth_set_sampling": (c_int, [c_int]),
     "sed_ms_kth_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

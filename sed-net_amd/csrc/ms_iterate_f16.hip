@@ -923,11 +923,22 @@ struct StageLayoutN {
 // accumulator row m = 16 a + 4 b + c  <->  image row sigma(m) = 16 a + 4 c + b (a 4 x 4 transpose inside every group of 16 rows)
 __host__ __device__ constexpr int sigma_row(int m) { return 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3); }
 
+// Stage image of the "E" kernel: the row-major planes + an fp8 (e4m3) image of the l plane TRANSPOSED, [128 features][32 keys],
+// 48-byte rows (conflict-free ds_read_b128: 12 dwords apart), for the fp8 correction term of the second product: byte p of
+// feature row f = fp8(2^6 l) of the key in image row sigma(m), m = mfma_row(p & 15, p >> 4) -- the k order in which a lane
+// pair's 16 + 16 weights of a stage form the B operand of v_mfma_f32_32x32x64_f8f6f4.
+struct StageLayoutE {
+    static constexpr int XROW = 272, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, OFF_T8 = 2 * XPLANE, T8ROW = 48,
+                         STAGE = 2 * XPLANE + 128 * T8ROW;                                                    // 23552 B
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");
+};
+
 // X [B, N, 128] fp32 -> row-major stage images [B, nst, 17408] (h plane | l plane, rows = keys in natural order, 272 B apart)
+template <bool E = false>                          // E: StageLayoutE images (row-major planes + fp8 transposed l plane)
 __global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict__ X, const float* __restrict__ bw,
                                                          uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
                                                          int nst) {
-    using L = StageLayoutN;
+    using L = std::conditional_t<E, StageLayoutE, StageLayoutN>;
     const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
     const float* Xc = X + (size_t)cloud * N * 128;
     uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
@@ -952,6 +963,18 @@ __global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict
         }
         *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
         *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+        if constexpr (E) {
+            const int m = sigma_row(kk);                                   // accumulator row of image row kk (sigma is an involution)
+            const int pb = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);   // m = mfma_row(r, hi): hi = (m >> 2) & 1, r = (m & 3) + 4 (m >> 3)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dst[StageLayoutE::OFF_T8 + (d0 + u) * StageLayoutE::T8ROW + pb] =
+                    (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32((float)ll[u] * 64.0f, 0.f, 0, false) & 0xFF);
+        }
+    }
+    if (E) {                                                  // pad bytes of the fp8 rows
+        for (int i = tid; i < 128 * 4; i += 256)
+            *(uint32_t*)(dst + StageLayoutE::OFF_T8 + (i >> 2) * StageLayoutE::T8ROW + 32 + 4 * (i & 3)) = 0u;
     }
     if (tid < 64) {                                          // the 16 pad bytes of every row (never read as data)
         const int kk = tid & 31, pl = tid >> 5;
@@ -961,7 +984,15 @@ __global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict
     if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
 }
 
-template <bool CHUNKED = false, bool PL = true>      // PL: see ms_iterate_d128_f16q_kernel
+// E (one-launch form, fp16-head weights only; "4.5 MFMAs"): the x_l term of the second product, a 2^-12 correction that only
+// needs ~5 % relative accuracy because it averages over the keys, runs on the fp8 matrix pipe at twice the rate --
+// v_mfma_f32_32x32x64_f8f6f4 takes 64 keys, so the blocks of a sweep are paired: the first block of a pair keeps its weights as
+// fp8 (2^8 p, 4 registers); a lane half's 32 k-slots are its own 16 keys of the first stage + its own 16 keys of the second, so
+// the second block's fp8 weights complete the B operand in place and four fp8 MFMAs add sum p8 l8 over both stages to O
+// (2^8 p x 2^6 2^11 x_l = the accumulator's 2^25 scale). The A operand comes from the fp8 transposed l planes of StageLayoutE
+// (16 bytes from the previous block's buffer, 16 from the current one): four stage buffers. The fp16 part of the second product is one MFMA per step (p~ x_h). tools/micro/fp8_mfma_probe.hip: operand layout,
+// 64 cycles per instruction beside fp16 MFMAs.
+template <bool CHUNKED = false, bool PL = true, bool E = false>      // PL: see ms_iterate_d128_f16q_kernel
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
@@ -970,9 +1001,12 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
                                                                       const float* __restrict__ Qin = nullptr,
                                                                       float* __restrict__ partO = nullptr,
                                                                       float* __restrict__ partS = nullptr,
-                                                                      int* __restrict__ lowq = nullptr) {
-    using L = StageLayoutN;
+                                                                      int* __restrict__ lowq = nullptr,
+                                                                      int blob_stride = 0 /* bytes between stage images; 0 = STAGE */) {
+    static_assert(!E || (!CHUNKED && !PL), "the fp8 correction exists for the one-launch heads-only form");
+    using L = std::conditional_t<E, StageLayoutE, StageLayoutN>;
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int NBUF = E ? 4 : 3;
     constexpr int RD = F16Q_RING_DISTANCE;                              // the operand ring runs RD steps ahead
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
@@ -985,7 +1019,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
     if (PL && lowq != nullptr && !lowq[cloud]) return;
     const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
     const int nst = (N + 31) >> 5;
-    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const size_t bstride = blob_stride ? (size_t)blob_stride : (size_t)STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * bstride;
     const int qrow = bx * 256 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
@@ -1020,18 +1055,19 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
     }
 
     // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 2 w, 2 w + 1 (immediate offset), wave 0 also piece 16
-    static_assert(NPIECE == 17, "piece distribution below is written for 17 pieces");
+    static_assert(NPIECE == (E ? 23 : 17), "piece distribution below is written for 17 / 23 pieces");
     const unsigned lane16 = lane * 16;
     auto stage_dma = [&](int st, int buf) {
-        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        const uint8_t* src = blob_c + (size_t)st * bstride;
         uint8_t* dst = lds + buf * STAGE;
         const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 2048 + lane16);
         const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 2048);
         __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * 1024 + lane16),
-                                             (__attribute__((address_space(3))) void*)(dst + 16 * 1024), 16, 0, 0);
+        if (E ? wave < 7 : wave == 0)                  // pieces 16 .. 22 (E) / piece 16
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (16 + (E ? wave : 0)) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (16 + (E ? wave : 0)) * 1024), 16, 0, 0);
     };
     // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
     auto advance = [&](int& st, bool& fwd) {
@@ -1096,7 +1132,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
         } else {
             const int c = (t - 8) >> 1, j = (t - 8) & 1;
             fa[t & 3] = tr8(base + OFF_XH, c, j);
-            fb[t & 3] = tr8(base + OFF_XL, c, j);
+            if (!E) fb[t & 3] = tr8(base + OFF_XL, c, j);
         }
     };
     // first product of a block outside the pipeline (first block of the launch and of every sweep: Q has just changed),
@@ -1122,7 +1158,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float rsum = 0.f;
-    int buf = 0;                                          // buffer of the current block = n % 3
+    int buf = 0;                                          // buffer of the current block = n % NBUF
+    // E: fp8 weights (2^8 p, byte r = accumulator row r) of this block and of the pair's first block; position in the sweep
+    // the B operand of the pair's fp8 MFMAs, assembled in place: dwords 0-3 = the first block's weights, 4-7 = the second's
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    v8i p8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned p8cur[E ? 4 : 1] = {};
+    int in_sweep = 0;
     i32x4 phv[2], plv[2];                                 // weights of the current block: two accumulator rows (fp16 pair) per dword
     f32x16 s_cur;
 #pragma unroll
@@ -1135,9 +1177,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
 
     for (int n = 0; n < total; ++n) {
         const uint8_t* base = lds + buf * STAGE;
-        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
         const uint8_t* nbase = lds + nbuf * STAGE;
-        const uint8_t* n2base = lds + (nbuf == 2 ? 0 : nbuf + 1) * STAGE;
+        const uint8_t* n2base = lds + (nbuf == NBUF - 1 ? 0 : nbuf + 1) * STAGE;
+        const int pbuf = buf == 0 ? NBUF - 1 : buf - 1;      // E: the previous block's buffer (its fp8 plane is still there)
         const int key0 = st_cur * 32;
         const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
         const bool has_next = n + 1 < total && !sweep_end;
@@ -1156,6 +1199,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
             }
             const h16x2 h = {(h16)p[0], (h16)p[1]};
             phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            if constexpr (E) {                                // bytes 2 t, 2 t + 1 of the lane's 16 fp8 weights
+                // (v_cvt_scalef32_pk_fp8_f32, which divides by a scale operand and would save the two multiplies, is slower here:
+                // 365 instead of 288 ms)
+                const float a8 = p[0] * 0.015625f, c8 = p[1] * 0.015625f;
+                if (t & 1) p8cur[t >> 1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a8, c8, (int)p8cur[t >> 1], true);
+                else p8cur[t >> 1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a8, c8, (int)p8cur[t >> 1], false);
+            }
             if (PL) {
                 const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
                 plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
@@ -1208,26 +1258,61 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
         // ---- phase 2: second product of block n. After step 13 nobody reads buffer n any more and everybody's pieces of
         // block n + 2 (issued a block ago) have landed: barrier, then block n + 3 -> buffer n, and the ring moves on to
         // block n + 2's first-product operands.
+        // E: this block closes a pair (odd position in the sweep), or it is the unpaired last block of a sweep. A lane's 32 k-slots
+        // of the fp8 MFMA are its OWN 16 keys of the first stage followed by its own 16 keys of the second (k = 32 hi + ...):
+        // the B operand is just the two blocks' fp8 weights side by side -- no exchange between the lane halves.
+        const bool pair_second = E && (in_sweep & 1) != 0;
+        const bool pair_flush = E && !pair_second && sweep_end;
+        if constexpr (E) {
+            if (pair_second) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p8[4 + i] = (int)p8cur[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { p8[i] = (int)p8cur[i]; p8[4 + i] = 0; }     // (flush: no second stage -> zero weights)
+            }
+        }
+        // fp8 transposed l plane, 16 bytes = this lane half's 16 keys of a stage: first stage from the previous block's buffer
+        // (flush: this block's), second stage from this block's
+        const uint8_t* t8a = lds + (pair_second ? pbuf : buf) * STAGE + (E ? StageLayoutE::OFF_T8 : 0) + li * 48 + 16 * hi;
+        const uint8_t* t8b = lds + buf * STAGE + (E ? StageLayoutE::OFF_T8 : 0) + li * 48 + 16 * hi;
+        // The fp8 A operand of feature tile cc is read one step before its MFMA (steps 9 .. 12, before the barrier of step 13).
+        const bool do8 = E && (pair_second || pair_flush);
+        v8i a8;
+        auto load_a8 = [&](int cc) {                          // two 16-byte reads straight into the halves of the 8-register operand
+            const i32x4 lo = *(const i32x4*)(t8a + cc * 32 * 48), hi4 = *(const i32x4*)(t8b + cc * 32 * 48);
+            a8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        if (do8) load_a8(0);
 #pragma unroll
         for (int t = 8; t < 16; ++t) {
             const int c = (t - 8) >> 1, j = (t - 8) & 1;
             const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
-            o[c] = mfma16(fb[t & 3], phj, o[c]);
+            if (!E) o[c] = mfma16(fb[t & 3], phj, o[c]);
             if (PL) {
                 const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
                 o[c] = mfma16(fa[t & 3], plj, o[c]);
             }
             o[c] = mfma16(fa[t & 3], phj, o[c]);
+            if constexpr (E) {
+                if (do8 && t >= 9 && t < 13) {                    // feature tile t - 9, 64 keys
+                    const int cc = t - 9;
+                    o[cc] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, p8, o[cc], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    if (cc < 3) load_a8(cc + 1);
+                }
+            }
             if (t + RD < 16) ring_load(t + RD, base);
             else if (n + 2 < total) ring_load(t + RD - 16, n2base);
             __builtin_amdgcn_sched_barrier(0);
             if (t == 15 - RD) {                            // the last step that loads from this block's buffer
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (n + 3 < total) stage_dma(st_dma, buf);
+                // three buffers: block n + 3 replaces block n; E: it replaces block n - 1, whose fp8 plane was read above
+                if (n + 3 < total) stage_dma(st_dma, E ? pbuf : buf);
                 advance(st_dma, fwd_dma);
             }
         }
+        if constexpr (E) in_sweep = sweep_end ? 0 : in_sweep + 1;
 
         advance(st_cur, fwd_cur);
         buf = nbuf;
@@ -2172,14 +2257,16 @@ int g_ms_f16_cfg = 0;
 
 static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
 
-// image formats: 0 = four planes, 32-key stages (StageLayout<32>); 2 = four planes, 64-key stages; 5 = row-major only (StageLayoutN)
+// image formats: 0 = four planes, 32-key stages (StageLayout<32>); 2 = four planes, 64-key stages; 5 = row-major only (StageLayoutN);
+// 8 = row-major + fp8 transposed l plane (StageLayoutE)
 static size_t f16_blob_bytes(int B, int N, int fmt) {
     const size_t kt = fmt == 2 ? 64 : 32;
-    const size_t stage = fmt == 2 ? StageLayout<64>::STAGE : fmt == 5 ? StageLayoutN::STAGE : StageLayout<32>::STAGE;
+    const size_t stage = fmt == 2 ? StageLayout<64>::STAGE : fmt == 5 ? StageLayoutN::STAGE : fmt == 8 ? StageLayoutE::STAGE
+                                                                                              : StageLayout<32>::STAGE;
     return (size_t)B * ((N + kt - 1) / kt) * stage;
 }
 // format the one-launch (unchunked) kernel of a configuration reads; the key-chunked form always reads format 0
-static int f16_unchunked_fmt(int cfg) { return cfg == 2 ? 2 : (cfg == 0 || cfg == 5) ? 5 : 0; }
+static int f16_unchunked_fmt(int cfg) { return cfg == 2 ? 2 : cfg == 8 ? 8 : (cfg == 0 || cfg == 5) ? 5 : 0; }
 
 // stage images | "rows not unit" flags | "weighted means cancel" flags (both per cloud, 256-byte blocks)
 size_t ms_f16_workspace_bytes(int B, int N) {
@@ -2276,12 +2363,37 @@ static int f16r_launch(int B, int N, int iters, const float* bw, const float* X,
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
     ms_iterate_d128_f16r_kernel<false, PL><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
         X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, PL ? nullptr : lowq);
     if (!PL)
         ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
             X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// the "4.5-MFMA" kernel: StageLayoutE images, four stage buffers; flagged clouds are redone by the (h, l) row-major kernel on the
+// same images (their row-major planes sit at the start of every stage)
+static int f16e_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       int* lowq, hipStream_t stream) {
+    using L = StageLayoutE;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, false, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_n_kernel<true><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16r_kernel<false, false, true><<<dim3((N + 255) / 256, B), 512, 4 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * StageLayoutN::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq, L::STAGE);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -2334,13 +2446,13 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         attr = true;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
-    const bool heads = g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7;
+    const bool heads = g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7 || g_ms_f16_cfg == 8;
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
         if (g_ms_f16_cfg == 6)
             ms_iterate_d128_f16q_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, 1, Q, partO, partS);
-        else if (g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7)
+        else if (g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7 || g_ms_f16_cfg == 8)
             ms_iterate_d128_f16q_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, 1, Q, partO, partS);
         else
@@ -2369,6 +2481,7 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
     if (g_ms_f16_cfg == 0) return f16r_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 8) return f16e_launch(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     if (g_ms_f16_cfg == 7) return f16q_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     if (g_ms_f16_cfg == 6) return f16q_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
     if (g_ms_f16_cfg == 5) return f16r_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
@@ -2419,8 +2532,8 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
             if (e != hipSuccess) return (int)e;
             attr = true;
         }
-        ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
-        ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+        ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_n_kernel<false><<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
         ms_iterate_d128_f16t_kernel<true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
         SED_LAUNCH_CHECK();
@@ -2460,7 +2573,7 @@ extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
 }
 
 extern "C" int sed_ms_set_f16_config(int cfg) {
-    if (cfg < 0 || cfg > 7) return SED_EINVAL;
+    if (cfg < 0 || cfg > 8) return SED_EINVAL;
     g_ms_f16_cfg = cfg;
     return SED_OK;
 }

@@ -52,8 +52,8 @@ def variant(request):
     lib.sed_ms_set_f16_sparse_config(2)
 
 
-@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "f16q", "f16x", "f16xc",
-                                     "sparse", "sparsex"],
+@pytest.mark.parametrize("variant", ["batched", "splitk", "chunked", "f16", "f16i", "f16g", "f16r", "f16v1", "f16b", "f16c", "f16q", "f16e", "f16x",
+                                     "f16xc", "sparse", "sparsex"],
                          indirect=True)
 @pytest.mark.parametrize("iters,key,atol", [(1, "newX_it1", 2e-6), (5, "newX_it5", 5e-6), (50, "newX_it50", 1e-5)])
 def test_iterations_match_golden(T, golden, iters, key, atol, variant):
@@ -185,6 +185,32 @@ def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
     assert (res["f16"][1] != res["f16r"][1]).any()                       # not flagged: the heads-only rows ...
     np.testing.assert_array_equal(res["f16"][1], alone)                  # ... the same as without flagged neighbours
     np.testing.assert_allclose(res["f16"][1], res["f16r"][1], atol=2e-6)
+
+
+def test_fp8_correction_kernel_matches_the_default(T):
+    """Experimental "f16e" kernel: the x_l term of the second product on the fp8 matrix pipe, blocks of a sweep
+    paired for its 64-key MFMAs (odd stage counts: the last block flushes alone), four stage buffers, flagged clouds redone by the
+    (h, l) kernel on the same images. Rows within 2e-6 of the default kernel after 1, 2 and 50 iterations, on stage counts of both
+    parities and with a ragged last stage; a cloud whose weighted means cancel carries the (h, l) kernel's bits."""
+    from sednet_hip import ops, synth
+    for N in (4099, 4128, 9973):                                 # 129 (odd), 129, 312 (even) stages
+        Xs = np.stack([synth.clustered_embedding(N=N, d=128, n_clusters=7 + c, sigma=0.02, seed=60 + c)[0] for c in range(2)])
+        rnd = T.nn.functional.normalize(T.randn(1, N, 128, generator=T.Generator().manual_seed(N)), dim=2)
+        X = T.cat([T.from_numpy(Xs), rnd]).cuda().contiguous()
+        bw = ops.ms_bandwidth(X, max(30, N // 67), 0.003)
+        for iters in (1, 2, 50):
+            try:
+                ops.ms_set_variant("f16")
+                ref = ops.ms_iterate(X, bw, iters).cpu().numpy()
+                ops.ms_set_variant("f16r")
+                hl = ops.ms_iterate(X, bw, iters).cpu().numpy()
+                ops.ms_set_variant("f16e")
+                got = ops.ms_iterate(X, bw, iters).cpu().numpy()
+            finally:
+                ops.ms_set_variant("auto")
+            np.testing.assert_allclose(got[:2], ref[:2], atol=2e-6)
+            np.testing.assert_array_equal(got[2], hl[2])                 # flagged (unstructured rows): the (h, l) pass
+            np.testing.assert_allclose(np.linalg.norm(got, axis=2), 1.0, atol=1e-6)
 
 
 def test_split_fp16_falls_back_for_non_unit_rows(T):

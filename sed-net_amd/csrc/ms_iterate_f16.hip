@@ -1841,12 +1841,12 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
 #ifndef F16T_REFGROUP
 #define F16T_REFGROUP 11                              // 11 x 9 KiB reference head planes <= 6 x 17 KiB of stage buffers
 #endif
-template <bool STAGGER>
+template <bool STAGGER, bool PL = true>      // PL = false: fp16-head weights (see ms_iterate_d128_f16q_kernel)
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq = nullptr) {
     using L = StageLayoutN;
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
@@ -1863,6 +1863,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
     int bx;
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;
     const float* Xc = X + (size_t)cloud * N * 128;
     const int nst = (N + 31) >> 5;
     const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
@@ -2103,11 +2104,15 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
                 float pmax = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    rsum += p[r];
                     pmax = fmaxf(pmax, p[r]);
                     const h16 h = (h16)p[r];
                     ph[r >> 3][r & 7] = h;
-                    pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    if (PL) {
+                        rsum += p[r];
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    } else {
+                        rsum += (float)h;
+                    }
                 }
                 // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
                 live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
@@ -2126,7 +2131,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
                 for (int t = 8; t < 16; ++t) {
                     const int c = (t - 8) >> 1, jj = (t - 8) & 1;
                     o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
-                    o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
                     o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
                     if (t + 2 < 16) ring_load(t + 2, base);
                     else if (j + 1 < ns) ring_load(t + 2 - 16, nbase);
@@ -2169,6 +2174,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
             }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
         if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
             float ch2 = 0.f;
             if (qrow < N) {
@@ -2501,7 +2507,8 @@ size_t ms_f16_sparse_workspace_bytes(int B, int N) {
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated).
 // g_ms_f16_sparse_cfg: 2 = ms_iterate_d128_f16s_kernel with fp16-head weights (5 MFMAs per block pair; default), 1 = the same with
-// (h, l) weights (6 MFMAs), 0 = ms_iterate_d128_f16t_kernel
+// (h, l) weights (6 MFMAs), 3 = the row-major kernel below with fp16-head weights (51.1 vs 46.9 ms: half the copy bytes do not
+// help the sparse schedule with either kind of weights), 0 = ms_iterate_d128_f16t_kernel
 // (row-major-only stage images, transpose reads, 6 buffers: half the copy traffic, and 8 % slower -- 54.6 vs 50.5 ms on the
 // 64-cloud clustered benchmark: the copies are not what holds the sparse kernel)
 int g_ms_f16_sparse_cfg = 2;
@@ -2510,7 +2517,7 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
                          float margin, unsigned long long* stats, hipStream_t stream) {
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
-    const int cfg = g_ms_f16_sparse_cfg == 0 ? 5 : 0;                  // image format of f16_blob_bytes
+    const int cfg = (g_ms_f16_sparse_cfg == 0 || g_ms_f16_sparse_cfg == 3) ? 5 : 0;      // image format of f16_blob_bytes
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes(B, N, cfg));
     uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
@@ -2521,21 +2528,31 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    if (g_ms_f16_sparse_cfg == 0) {
+    if (g_ms_f16_sparse_cfg == 0 || g_ms_f16_sparse_cfg == 3) {
         using L = StageLayoutN;
         constexpr int smem = F16T_NBUF * L::STAGE > F16T_REFGROUP * F16S_REFBYTES ? F16T_NBUF * L::STAGE
                                                                                  : F16T_REFGROUP * F16S_REFBYTES;
         static bool attr = false;
         if (!attr) {
-            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true>,
+            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
             attr = true;
         }
         ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
         ms_split_n_kernel<false><<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
-        ms_iterate_d128_f16t_kernel<true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+        if (g_ms_f16_sparse_cfg == 3) {        // fp16-head weights; flagged clouds again with (h, l) weights
+            ms_iterate_d128_f16t_kernel<true, false><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq);
+            ms_iterate_d128_f16t_kernel<true, true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq);
+        } else {
+            ms_iterate_d128_f16t_kernel<true, true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+        }
         SED_LAUNCH_CHECK();
         return SED_OK;
     }
@@ -2567,7 +2584,7 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
 }
 
 extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
-    if (cfg < 0 || cfg > 2) return SED_EINVAL;
+    if (cfg < 0 || cfg > 3) return SED_EINVAL;
     g_ms_f16_sparse_cfg = cfg;
     return SED_OK;
 }

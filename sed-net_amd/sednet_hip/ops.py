@@ -260,8 +260,11 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     # one k-means step: reference directions = normalised means of the pivot groups (any unit vectors are valid
     # references; the mean sits in the middle of its group, which tightens every angular bound by about a third)
     grp = dots.argmax(2)
-    piv = torch.zeros((B, P, D), dtype=torch.float32, device=X.device).scatter_add_(
-        1, grp.unsqueeze(-1).expand(B, N, D), X)
+    # (group sums as a one-hot matrix product, not scatter_add_: float atomics add in a different order every run, the means
+    # change in their last bits, a row near two pivots changes group, the row order changes -- and with it the summation order
+    # of the whole block-sparse pass: results were not bit-reproducible from run to run)
+    onehot = torch.nn.functional.one_hot(grp, P).to(X.dtype)                  # [B,N,P]
+    piv = torch.bmm(onehot.transpose(1, 2), X)
     piv = torch.nn.functional.normalize(piv, dim=2).contiguous()
     dots = torch.bmm(X, piv.transpose(1, 2))
     grp = dots.argmax(2)

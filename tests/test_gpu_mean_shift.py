@@ -404,6 +404,27 @@ def test_block_sparse_split_fp16_edges(T, N):
         np.testing.assert_array_equal(ops.ms_iterate(Xb, bw[:1], 1).cpu().numpy(), d1)
 
 
+def test_every_schedule_is_bit_reproducible(T):
+    """The same call twice returns the same bits, for every schedule the planner can pick -- including the block-sparse one,
+    whose row order comes from a pivot sort (its group means were float atomics once: the order, hence the summation order of
+    the whole pass, changed from run to run)."""
+    from sednet_hip import ops, synth
+    X = dev(T, np.stack([synth.clustered_embedding(N=10000, d=128, n_clusters=11 + c, sigma=0.02, seed=700 + c)[0] for c in range(4)]))
+    bw = ops.ms_bandwidth(X, 150, 0.003)
+    assert T.equal(ops.ms_bandwidth(X, 150, 0.003), bw)
+    try:
+        for v in ("auto", "f16", "f16c", "f16e"):
+            ops.ms_set_variant(v)
+            ref = ops.ms_iterate(X, bw, 8)
+            for _ in range(4):
+                assert T.equal(ops.ms_iterate(X, bw, 8), ref), v
+    finally:
+        ops.ms_set_variant("auto")
+    o0 = ops.ms_pivot_order(X)
+    for _ in range(4):
+        assert all(T.equal(a, b) for a, b in zip(o0, ops.ms_pivot_order(X)))
+
+
 def test_row_major_only_stage_images(T):
     """The experimental kernels on 17 KiB row-major-only stage images (second-product operands by ds_read_b64_tr_b16, no
     transposed planes): dense ("f16r") and block-sparse (sed_ms_set_f16_sparse_config(0)) against the default kernels --

@@ -174,12 +174,11 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
                         bm[i][r] = lo_;
                     }
                 } else {
-                    if (dv <= Tf && !pad) {
+                    if (dv <= Tf && !pad) {                      // one branch per value; inside it the append is predicated
                         const uint32_t key = f32_sortable(dv);
-                        if (key <= T) {
-                            if (cnt < CAPK) mylist[cnt] = key;
-                            ++cnt;
-                        }
+                        const bool hit = key <= T;
+                        if (hit && cnt < CAPK) mylist[cnt] = key;
+                        cnt += hit ? 1 : 0;
                     }
                 }
             }

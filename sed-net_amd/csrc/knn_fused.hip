@@ -190,12 +190,12 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
                         bm[i][r] = lo_;
                     }
                 } else {
-                    if (dv <= Tf && !pad) {
+                    if (dv <= Tf && !pad) {                      // one branch per value; inside it the append is predicated
                         const uint32_t key = f32_sortable(dv);
-                        if (key <= T) {
-                            if (cnt < CAPL) { Cand c; c.key = key; c.idx = tile * 32 + krow; mylist[cnt] = c; }
-                            ++cnt;
-                        }
+                        const bool hit = key <= T;
+                        Cand c; c.key = key; c.idx = tile * 32 + krow;
+                        if (hit && cnt < CAPL) mylist[cnt] = c;
+                        cnt += hit ? 1 : 0;
                     }
                 }
             }
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
                 for (int i = 0; i < M; ++i) { const uint32_t lo_ = min(bm[i][r], key); key = max(bm[i][r], key); bm[i][r] = lo_; }
             } else {
                 if (key <= T && key != 0xFFFFFFFFu) {
-                    if (cnt < 2 * CAPL) { Cand c; c.key = key; c.idx = tile * 32 + r; mylist[cnt] = c; }
+                    Cand c; c.key = key; c.idx = tile * 32 + r;
+                    if (cnt < 2 * CAPL) mylist[cnt] = c;
                     ++cnt;
                 }
             }

@@ -105,12 +105,15 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
 #pragma unroll
             for (int g = 0; g < 4; ++g) ck4[g] = *(const f32x4*)&cks[cur][8 * g + 4 * hi];
         }
+        // A lane meets its centres in ascending index order (rows ascend with r, tiles with the loop), so "first minimum" is the
+        // strict comparison alone; only the cloud's last, partly filled tile tests the index against N.
+        const bool ragged = tile * 32 + 32 > N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = tile * 32 + mfma_row(r, hi);
             const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
             const float dist = 2.0f - dot2;
-            if (ci < N && (dist < best || (dist == best && ci < besti))) { best = dist; besti = ci; }
+            if (dist < best && (!ragged || ci < N)) { best = dist; besti = ci; }
         }
         if (tile + 1 < ntiles) stage_store(cur ^ 1);
         __syncthreads();

@@ -247,16 +247,20 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
 // mean / rstd per (cloud, group) from per-block, per-32-channel-tile partial sums (fixed order, fp64)
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
                                    float eps, float* __restrict__ stats /*[B][G][2]*/) {
-    const int cloud = blockIdx.x, g = threadIdx.x;
-    if (g >= G) return;
-    const int tpg = ntile / G;
+    // one wave per (cloud, group): lane l adds entries l, l + 64, ... of the group's nblk x tpg partial pairs, then a fixed
+    // xor tree over the lanes (the serial loop of one thread per group was 22-35 us of dependent loads per launch)
+    const int cloud = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const int tpg = ntile / G, n = nblk * tpg;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b)
-        for (int t = g * tpg; t < (g + 1) * tpg; ++t) {
-            const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
-            s += pp[0];
-            q += pp[1];
-        }
+    for (int e = lane; e < n; e += 64) {
+        const int b = e / tpg, t = g * tpg + (e - b * tpg);
+        const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
+        s += pp[0];
+        q += pp[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (lane != 0) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -313,7 +317,7 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
         return SED_EUNSUPPORTED;
     }
     SED_LAUNCH_CHECK();
-    gn_finalize_kernel<<<B, 64, 0, stream>>>(part, nblk, Cout / 32, G, (double)(Cout / G) * N * k, eps, stats);
+    gn_finalize_kernel<<<dim3(B, G), 64, 0, stream>>>(part, nblk, Cout / 32, G, (double)(Cout / G) * N * k, eps, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -387,16 +387,20 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
 
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
                                    float eps, float* __restrict__ stats) {
-    const int cloud = blockIdx.x, g = threadIdx.x;
-    if (g >= G) return;
-    const int tpg = ntile / G;
+    // one wave per (cloud, group): lane l adds entries l, l + 64, ... of the group's nblk x tpg partial pairs, then a fixed
+    // xor tree over the lanes (the serial loop of one thread per group was 22-35 us of dependent loads per launch)
+    const int cloud = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const int tpg = ntile / G, n = nblk * tpg;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b)
-        for (int t = g * tpg; t < (g + 1) * tpg; ++t) {
-            const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
-            s += pp[0];
-            q += pp[1];
-        }
+    for (int e = lane; e < n; e += 64) {
+        const int b = e / tpg, t = g * tpg + (e - b * tpg);
+        const double* pp = part + (((size_t)cloud * nblk + b) * ntile + t) * 2;
+        s += pp[0];
+        q += pp[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (lane != 0) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -657,7 +661,7 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
 extern "C" int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps, const void* partials,
                                    float* stats, hipStream_t stream) {
     if (B <= 0 || G <= 0 || G > 64 || !partials || !stats || (Coutp / 32) % G != 0) return SED_EINVAL;
-    gn_finalize_kernel<<<B, 64, 0, stream>>>((const double*)partials, (N + 127) / 128, Coutp / 32, G, count, eps, stats);
+    gn_finalize_kernel<<<dim3(B, G), 64, 0, stream>>>((const double*)partials, (N + 127) / 128, Coutp / 32, G, count, eps, stats);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -2254,8 +2254,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
 // cfg 0 (default): software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1) with fp16-head
 // weights in the second product (5 MFMAs per block pair) -- on row-major-only stage images (ms_iterate_d128_f16r_kernel, 17 KiB
-// per stage, transpose reads) in its one-launch form, on four-plane images (ms_iterate_d128_f16q_kernel) in its key-chunked
-// form; 7: the four-plane kernel in both forms; 6 / 5: four-plane / row-major kernel with (h, l) weights (6 MFMAs);
+// per stage, transpose reads) in its one-launch and its key-chunked form; 7: the four-plane kernel
+// (ms_iterate_d128_f16q_kernel) in both forms; 6 / 5: four-plane / row-major kernel with (h, l) weights (6 MFMAs);
 // 1: round-2 pipelined kernel, wave groups in phase; 4: the same, groups half a block out of phase (the default until the
 // software-pipelined kernel); 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave
 // workgroups per CU
@@ -2449,7 +2449,30 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
         attr = true;
+    }
+    if (g_ms_f16_cfg == 0) {          // default: key-chunked form on row-major-only stage images like the one-launch form (-2 .. 5 %
+                                      // against the four-plane kernel below, cfg 7; the blob region stays sized for four planes)
+        using LN = StageLayoutN;
+        ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        for (int it = 0; it < iters; ++it) {
+            const float* Q = it == 0 ? X : newX;
+            ms_iterate_d128_f16r_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * LN::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+            const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, lowq, stream);
+            if (rc != SED_OK) return rc;
+        }
+        if (iters > 0)
+            ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * LN::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+        SED_LAUNCH_CHECK();
+        return SED_OK;
     }
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     const bool heads = g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7 || g_ms_f16_cfg == 8;

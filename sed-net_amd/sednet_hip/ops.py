@@ -422,14 +422,14 @@ def ms_set_variant(variant):
     "f16g" / "f16i" = the earlier pipelined kernel with wave groups half a block out of phase / in phase, "f16v1" / "f16b" =
     the first, unpipelined version with 64-key / 32-key stages). "f16" / "f16c" feed the weights into the second product and the
     row sum as their fp16 heads only (5 MFMAs per block pair); "f16" reads row-major-only stage images (transpose reads for the
-    second product), "f16q" is the same arithmetic on four-plane images (what "f16c" reads); "f16x" / "f16xc" / "f16r" = the
+    second product), "f16q" / "f16qc" are the same arithmetic on four-plane images (one-launch / key-chunked form); "f16x" / "f16xc" / "f16r" = the
     four-plane / key-chunked / row-major kernels with (h, l) weights (6 MFMAs), like all the earlier versions. "f16e" = the
     experimental form of "f16" whose x_l correction term runs on the fp8 matrix pipe (4.5 MFMAs per block pair; not faster)."""
     global _MS_VARIANT
     _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
-    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5, "f16x": 6, "f16xc": 6, "f16q": 7, "f16e": 8}.get(
+    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5, "f16x": 6, "f16xc": 6, "f16q": 7, "f16qc": 7, "f16e": 8}.get(
         variant, 0 if _MS_WEIGHT_DIGITS == 1 else 6)), "ms_set_f16_config")
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5, "f16xc": 5}.get(variant, 4)),
+    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5, "f16xc": 5, "f16qc": 5}.get(variant, 4)),
           "ms_set_variant")
 
 

@@ -249,18 +249,21 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     const float xxi = __fadd_rn(__fadd_rn(__fmul_rn(p0, p0), __fmul_rn(p1, p1)), __fmul_rn(p2, p2));
     const int ntiles = (N + 31) >> 5;
 
-    uint32_t bm[M][32];
+    // bucket minima as floats, float prefilter in sweep 2, padding tests only in the last tile: see knn_sweep_kernel
+    float bm[M][32];
     if (PASS == 1) {
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int r = 0; r < 32; ++r) bm[i][r] = 0xFFFFFFFFu;
+            for (int r = 0; r < 32; ++r) bm[i][r] = 3.0e38f;
     }
     uint32_t T = 0;
+    float Tf = 0.f;
     int cnt = 0;
     Cand* mylist = nullptr;
     if (PASS == 2) {
         T = Tbuf[(size_t)cloud * N + qc];
+        Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);
         mylist = lists + (((size_t)cloud * N + qc) * gridDim.z + blockIdx.z) * 2 * CAPL;       // one thread owns both halves
     }
     const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
@@ -285,29 +288,47 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     for (int tile = t0; tile < t1; tile += tstep) {
         cur ^= 1;
         if (tile + tstep < t1) stage(tile + tstep, cur ^ 1);
+        const bool ragged = tile * 32 + 32 > N;
+        auto values = [&](auto ragged_c) {
+            constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const float* kq = ks[cur][r];
-            const float dotp = fmaf(p2, kq[2], fmaf(p1, kq[1], __fmul_rn(p0, kq[0])));
-            const float dotn = fmaf(n2, kq[5], fmaf(n1, kq[4], __fmul_rn(n0, kq[3])));
-            const float dp = __fadd_rn(__fsub_rn(kq[6], 2.0f * dotp), xxi);          // (xx_j - inner) + xx_i  (:109)
-            const float dn = __fsub_rn(2.0f, 2.0f * dotn);                           // :112
-            const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));       // :115
-            uint32_t key = kq[7] != 0.f ? f32_sortable(dv) : 0xFFFFFFFFu;
-            if (PASS == 1) {
+            for (int r = 0; r < 32; ++r) {
+                const float* kq = ks[cur][r];
+                const float dotp = fmaf(p2, kq[2], fmaf(p1, kq[1], __fmul_rn(p0, kq[0])));
+                const float dotn = fmaf(n2, kq[5], fmaf(n1, kq[4], __fmul_rn(n0, kq[3])));
+                const float dp = __fadd_rn(__fsub_rn(kq[6], 2.0f * dotp), xxi);          // (xx_j - inner) + xx_i  (:109)
+                const float dn = __fsub_rn(2.0f, 2.0f * dotn);                           // :112
+                const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));       // :115
+                const bool pad = RAGGED && kq[7] == 0.f;
+                if (PASS == 1) {
+                    float v = pad ? 3.0e38f : dv;
 #pragma unroll
-                for (int i = 0; i < M; ++i) { const uint32_t lo_ = min(bm[i][r], key); key = max(bm[i][r], key); bm[i][r] = lo_; }
-            } else {
-                if (key <= T && key != 0xFFFFFFFFu) {
-                    Cand c; c.key = key; c.idx = tile * 32 + r;
-                    if (cnt < 2 * CAPL) mylist[cnt] = c;
-                    ++cnt;
+                    for (int i = 0; i < M; ++i) {
+                        const float lo_ = sed_vmin(bm[i][r], v);
+                        if (i + 1 < M) v = sed_vmax(bm[i][r], v);
+                        bm[i][r] = lo_;
+                    }
+                } else {
+                    if (dv <= Tf && !pad) {
+                        const uint32_t key = f32_sortable(dv);
+                        const bool hit = key <= T;
+                        Cand c; c.key = key; c.idx = tile * 32 + r;
+                        if (hit && cnt < 2 * CAPL) mylist[cnt] = c;
+                        cnt += hit ? 1 : 0;
+                    }
                 }
             }
-        }
+        };
+        if (ragged) values(std::true_type{});
+        else values(std::false_type{});
         __syncthreads();
     }
     if (PASS == 1) {
+        uint32_t bk[M][32];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bk[i][r] = bm[i][r] >= 3.0e38f ? 0xFFFFFFFFu : f32_sortable(bm[i][r]);
         uint32_t lo = 0, hiv = 0xFFFFFFFFu;
         for (int it = 0; it < 32; ++it) {
             const uint32_t mid = lo + ((hiv - lo) >> 1);
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int r = 0; r < 32; ++r) c += bm[i][r] <= mid ? 1 : 0;
+                for (int r = 0; r < 32; ++r) c += bk[i][r] <= mid ? 1 : 0;
             if (lo < hiv) { if (c >= k) hiv = mid; else lo = mid + 1; }
         }
         if (qi < N) Tbuf[(size_t)cloud * N + qi] = lo;

@@ -37,6 +37,8 @@ class _StageTimer:
 
 class SegmentationPipeline:
     stage_times = None            # set to a list to collect per-stage event pairs (bench.py)
+    TWO_STREAM_MAX_CLOUDS = 2     # up to this many clouds per call the two models' forwards run on two HIP streams
+    _side = None
 
     def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True, dist=None):
         """dist: an initialised torch.distributed (world > 1) -> the guard loop's retry passes are balanced over the
@@ -56,12 +58,32 @@ class SegmentationPipeline:
             idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
             if ev is not None:
                 ev.mark("input_graph")
-            _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
-            t_model = ops.row_argmax(log_prob, log_prob.shape[2])
-            if ev is not None:
-                ev.mark("type_model")
-            emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
-            X = ops.row_normalize(emb, emb.shape[2])
+            if x6.shape[0] <= self.TWO_STREAM_MAX_CLOUDS:
+                # Few clouds per call: a forward's kernels are 79-workgroup grids per cloud that leave most of the 256 CUs idle,
+                # and the two models are independent until the type vote -- the type model runs on a side stream beside the
+                # instance model (every op launches on torch's current stream). One cloud per call: 10.6 -> 9.9 ms (the host enqueues
+                # the two forwards one after the other, so the overlap is partial).
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
+                    t_model = ops.row_argmax(log_prob, log_prob.shape[2])
+                emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
+                X = ops.row_normalize(emb, emb.shape[2])
+                main.wait_stream(self._side)
+                log_prob.record_stream(main)
+                t_model.record_stream(main)
+                if ev is not None:
+                    ev.mark("type_model")
+            else:
+                _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
+                t_model = ops.row_argmax(log_prob, log_prob.shape[2])
+                if ev is not None:
+                    ev.mark("type_model")
+                emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
+                X = ops.row_normalize(emb, emb.shape[2])
         finally:
             ops.DEFERRED_KNN_FLAGS = prev
         return log_prob, t_model, emb, edges, X, flags

@@ -192,3 +192,30 @@ def test_pipeline_outputs_are_bit_reproducible(T):
                 else:
                     np.testing.assert_array_equal(np.asarray(v), np.asarray(ref[key]), err_msg=key)
     assert int(np.asarray(ref["passes"]).max()) >= 2          # (second leg: the guard cloud took a retry pass)
+
+
+def test_two_stream_forwards_give_the_same_outputs(T):
+    """Up to two clouds per call the type model runs on a side stream beside the instance model: same tensors as the
+    single-stream order, call after call (stream hand-offs and allocator reuse included)."""
+    from sednet_hip import synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    import bench
+    x = T.from_numpy(synth.batch_clouds(2, 10000, seed0=4321)[0]).cuda()
+    m_type, m_inst = bench.build_models(20, T.device("cuda"))
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=20)
+    assert pipe.TWO_STREAM_MAX_CLOUDS >= 2
+    try:
+        pipe.TWO_STREAM_MAX_CLOUDS = 0
+        np.random.seed(0)
+        ref = [pipe(x[i:i + 1]) for i in range(2)] + [pipe(x)]
+    finally:
+        pipe.TWO_STREAM_MAX_CLOUDS = SegmentationPipeline.TWO_STREAM_MAX_CLOUDS
+    for _ in range(3):
+        np.random.seed(0)
+        got = [pipe(x[i:i + 1]) for i in range(2)] + [pipe(x)]
+        for a, b in zip(got, ref):
+            for key, v in a.items():
+                if T.is_tensor(v):
+                    assert T.equal(v, b[key]), key
+                else:
+                    np.testing.assert_array_equal(np.asarray(v), np.asarray(b[key]), err_msg=key)

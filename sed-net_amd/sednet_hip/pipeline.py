@@ -62,7 +62,8 @@ class SegmentationPipeline:
                 # Few clouds per call: a forward's kernels are 79-workgroup grids per cloud that leave most of the 256 CUs idle,
                 # and the two models are independent until the type vote -- the type model runs on a side stream beside the
                 # instance model (every op launches on torch's current stream). One cloud per call: 10.6 -> 9.9 ms (the host enqueues
-                # the two forwards one after the other, so the overlap is partial).
+                # the two forwards one after the other, so the overlap is partial; enqueuing the type model from a second host thread is
+                # slower, 12.5 ms: the wrappers are Python-bound and fight over the GIL).
                 main = torch.cuda.current_stream()
                 if self._side is None:
                     self._side = torch.cuda.Stream()

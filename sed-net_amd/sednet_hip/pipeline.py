@@ -39,6 +39,8 @@ class SegmentationPipeline:
     stage_times = None            # set to a list to collect per-stage event pairs (bench.py)
     TWO_STREAM_MAX_CLOUDS = 2     # up to this many clouds per call the two models' forwards run on two HIP streams
     _side = None
+    _graphs = None
+    _graph_ok = True
 
     def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True, dist=None):
         """dist: an initialised torch.distributed (world > 1) -> the guard loop's retry passes are balanced over the
@@ -50,6 +52,17 @@ class SegmentationPipeline:
 
     def _forwards(self, x6, ev=None):
         """both models on x6 -> (log_prob, t_model, emb, edges, X, overflow flags)"""
+        if (self.GRAPH_FORWARDS and ops.FUSED_KNN and x6.shape[0] <= self.TWO_STREAM_MAX_CLOUDS and ev is not None
+                and ev.sink is None and self._graph_ok):
+            try:
+                return self._graph_forwards(x6)
+            except Exception as e:                                   # capture not possible here: the two-stream order below
+                import warnings
+                warnings.warn(f"SegmentationPipeline: HIP-graph capture of the forwards failed ({e!r}); using the two-stream order")
+                self._graph_ok = False
+        return self._forwards_plain(x6, ev)
+
+    def _forwards_plain(self, x6, ev=None):
         flags = []
         prev, ops.DEFERRED_KNN_FLAGS = ops.DEFERRED_KNN_FLAGS, flags
         try:
@@ -87,6 +100,55 @@ class SegmentationPipeline:
                 X = ops.row_normalize(emb, emb.shape[2])
         finally:
             ops.DEFERRED_KNN_FLAGS = prev
+        return log_prob, t_model, emb, edges, X, flags
+
+    # ---- few clouds per call: both forwards as ONE HIP graph with the type model forked onto a side stream -----------------
+    # Replaying removes the host from the picture: the two models' kernels (79-workgroup grids at one cloud) are queued on
+    # their two streams at once and really run side by side -- the plain two-stream order is limited by the host enqueuing one
+    # forward after the other. One graph per input shape; the outputs live in the graph's memory pool and are copied out.
+    GRAPH_FORWARDS = True
+
+    def _graph_forwards(self, x6):
+        # (a graph bakes in the addresses of the models' cached weight images: keyed by the parameters' identity / version, and the
+        # entry keeps those caches alive)
+        # (SEDNet._signature covers the encoder's parameters too: it walks self.parameters())
+        key = (tuple(x6.shape), self.model_type._signature(), self.model_inst._signature())
+        ent = self._graphs.get(key) if self._graphs is not None else None
+        if ent is None:
+            if self._graphs is None:
+                self._graphs = {}
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            static_x = x6.clone()
+            self._forwards_plain(static_x)                        # warm-up outside the capture: weight images, kernel attributes
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            flags = []
+            prev, ops.DEFERRED_KNN_FLAGS = ops.DEFERRED_KNN_FLAGS, flags
+            try:
+                with torch.cuda.graph(g):
+                    cap = torch.cuda.current_stream()
+                    e0, e1 = self.model_type.encoder, self.model_inst.encoder
+                    idx1 = e0.input_graph(static_x) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+                    self._side.wait_stream(cap)
+                    with torch.cuda.stream(self._side):
+                        _, log_prob, _ = self.model_type.forward_point_major(static_x, idx1)
+                        t_model = ops.row_argmax(log_prob, log_prob.shape[2])
+                    emb, _, edges = self.model_inst.forward_point_major(static_x, idx1)
+                    X = ops.row_normalize(emb, emb.shape[2])
+                    cap.wait_stream(self._side)
+            finally:
+                ops.DEFERRED_KNN_FLAGS = prev
+            keep = (self.model_type._prepared(), self.model_type.encoder._prepared(), self.model_inst._prepared(),
+                    self.model_inst.encoder._prepared())
+            if len(self._graphs) >= 4:                            # a handful of shapes at most; older graphs are dropped
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = (g, static_x, (log_prob, t_model, emb, edges, X), flags, keep)
+            self._graphs[key] = ent
+        g, static_x, outs, flags = ent[:4]
+        static_x.copy_(x6)
+        g.replay()
+        log_prob, t_model, emb, edges, X = (o.clone() for o in outs)
         return log_prob, t_model, emb, edges, X, flags
 
     def _forwards_checked(self, x6, ev=None):

@@ -219,3 +219,29 @@ def test_two_stream_forwards_give_the_same_outputs(T):
                     assert T.equal(v, b[key]), key
                 else:
                     np.testing.assert_array_equal(np.asarray(v), np.asarray(b[key]), err_msg=key)
+
+
+def test_graph_forwards_follow_weight_updates(T):
+    """The one- / two-cloud path replays both forwards from a HIP graph that bakes in the cached weight images: changing a
+    model's parameters must give a new graph (same outputs as the plain order with the new weights), not stale results."""
+    import warnings
+    from sednet_hip import synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    import bench
+    x = T.from_numpy(synth.batch_clouds(1, 4096, seed0=99)[0]).cuda()
+    m_type, m_inst = bench.build_models(20, T.device("cuda"))
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                          # a failed capture would only warn and fall back: make it fail
+        a = pipe(x)
+        assert pipe._graphs is not None and len(pipe._graphs) == 1
+        with T.no_grad():
+            m_inst.mlp_seg_prob2.weight.mul_(1.5)               # in-place update: parameter version changes
+        b = pipe(x)
+        assert len(pipe._graphs) == 2
+    try:
+        pipe.GRAPH_FORWARDS = False
+        ref = pipe(x)
+    finally:
+        pipe.GRAPH_FORWARDS = True
+    assert T.equal(b["labels"], ref["labels"]) and T.equal(b["bw"], ref["bw"]) and not T.equal(a["bw"], b["bw"])

@@ -37,7 +37,9 @@ class _StageTimer:
 
 class SegmentationPipeline:
     stage_times = None            # set to a list to collect per-stage event pairs (bench.py)
-    TWO_STREAM_MAX_CLOUDS = 2     # up to this many clouds per call the two models' forwards run on two HIP streams
+    # up to this many clouds per call the two models' forwards run on two HIP streams (tools/small_batch_streams.py: 1.07 x at
+    # one cloud per call, 1.10 x at 2, 1.06 x at 4, 1.02 x at 8, 1.01 x at 16; beyond, every kernel fills the chip on its own)
+    TWO_STREAM_MAX_CLOUDS = 16
     _side = None
     _graphs = None
     _graph_ok = True

@@ -7,7 +7,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the comment says "host"; the caller owns every buffer;
- *     the library allocates nothing and keeps no global state (re-entrant).
+ *     the library allocates nothing and keeps no global state (re-entrant): every behavioural choice (schedule, number of
+ *     weight digits, sampling stride, product arithmetic) is an ARGUMENT of the call it affects.
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); all work is enqueued on it,
  *     nothing synchronises.
  *   - return value: 0 = success, SED_EINVAL (-1) bad argument, SED_EUNSUPPORTED (-2) size outside the
@@ -81,48 +82,47 @@ int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, 
  * the materialised path for that cloud.
  * src/mean_shift.py:115-137 (compute_bandwidth: dist = 2 - 2 X X^T, topk(K)). */
 int sed_ms_kth_fused_max_k(int N);
-/* first-sweep sampling of clouds of >= 8192 points: 4 = every fourth key tile (default), 2 = every other one (results identical:
- * the second sweep verifies the threshold and flags the cloud otherwise) */
-int sed_ms_kth_set_sampling(int stride);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
+/* sampling: first sweep of clouds of >= 8192 points on every fourth key tile (0 = default, or 4) or on every other one (2);
+ * results identical (the second sweep verifies the threshold and flags the cloud otherwise) */
 int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                         int* overflow, sed_stream_t stream);
+                         int* overflow, int sampling, sed_stream_t stream);
 /* `iters` gaussian mean-shift iterations on unit rows, X [B,N,d] -> newX [B,N,d]; bw [B] on device.
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                        sed_stream_t stream);
-/* Same, with a caller-owned workspace of sed_ms_iterate_workspace_bytes(B, N, d) bytes (0 = none needed): small
- * batches at d = 128 (the reference script's one cloud per call) then run the key-chunked variant, which splits the
- * key sweep of every 128-query block over several workgroups per iteration so that all CUs have work. */
-size_t sed_ms_iterate_workspace_bytes(int B, int N, int d);
-/* the schedule sed_ms_iterate_ws_f32 takes for this shape when given that workspace: 1 batched fp32, 2 split-key fp32,
- * 3 key-chunked fp32, 4 split-fp16, 5 key-chunked split-fp16 (sed_ms_set_variant); 0 = unsupported shape */
-int sed_ms_iterate_plan(int B, int N, int d);
+/* Options of the iteration entry points, passed PER CALL (NULL = all defaults); nothing is remembered between calls.
+ * schedule (d = 128 has several that differ only in the order tile contributions are summed):
+ *   0 choose by size (default: split-fp16 whenever the workspace is given, its key-chunked form when few clouds would leave CUs
+ *     idle), 1 batched fp32 (one workgroup = 128 queries, all keys, all iterations), 2 split-key fp32 (32 queries, keys split over
+ *     8 waves), 3 key-chunked fp32, 4 split-fp16 one launch, 5 key-chunked split-fp16 (one launch pair per iteration).
+ *   split-fp16 (ms_iterate_f16.hip): the two fp32 products evaluated as fp16 MFMAs on round-to-nearest (h, l) splits of the fp32
+ *   operands -- dropped terms <= 3 * 2^-24 relative, fp32 accumulation; clouds whose rows are not unit vectors fall back to the
+ *   exact fp32 kernel on the device.
+ * weight_digits: fp16 digits of the kernel weights in the split-fp16 second product: 0 / 1 = fp16 heads, consistently in
+ *   numerator and row sum (5 MFMAs per 32 x 32 x 128 block pair; clouds in which a weighted mean nearly cancels are flagged on the
+ *   device and redone with 2 digits), 2 = (h, l) pairs everywhere (6 MFMAs; fp32-equivalent). */
+typedef struct sed_ms_options {
+    int schedule;
+    int weight_digits;
+} sed_ms_options_t;
+/* Same, with a caller-owned workspace of sed_ms_iterate_workspace_bytes(B, N, d, opt) bytes (0 = none needed). */
+size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options_t* opt);
+/* the schedule sed_ms_iterate_ws_f32 takes for this shape and these options when given that workspace (values as
+ * sed_ms_options_t.schedule, 1 .. 5); 0 = unsupported shape or options */
+int sed_ms_iterate_plan(int B, int N, int d, const sed_ms_options_t* opt);
 int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                          void* workspace, size_t workspace_bytes, sed_stream_t stream);
-/* Opt-in block-sparse schedule (d = 128): identical arithmetic, except that a wave skips a 32 x 32 (keys x queries) block
- * whose exponent arguments -dist/(2 b^2) are ALL below skip_below (< 0). With skip_below = -30 every dropped kernel
- * weight is <= 9.4e-14, so a row sum (>= 1, the self weight) changes by <= N e^-30 relative: <= 1e-9 at N = 10 000,
- * 60 x below fp32 resolution. Effective when rows are ordered so that blocks are cluster-pure (the Python wrapper sorts
- * by nearest pivot and restores the order); nothing is skipped on unstructured data. */
-int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                              float skip_below, sed_stream_t stream);
-/* Second level of the block-sparse schedule: blocks are skipped BEFORE the first product when a geometric bound proves
- * that all their weights are <= e^skip_below. Rows sorted by nearest of P pivot rows; row_piv [B,N] = that pivot; per
- * 32-row tile t: tile_rp[t] = a reference pivot, tile_alpha[t] = max angle (rad) between a row of the tile and it;
- * piv [B,P,128]; pang [B,P,P] pivot-pivot angles. Each iteration a query measures beta = its angle to its own pivot a;
- * angle(q, x) >= pang[a][rp[t]] - beta - alpha[t] (triangle inequality on the unit sphere) is compared with
- * acos(1 + skip_below b^2) + margin. N <= 16 384, d = 128. */
-int sed_ms_iterate_bounds_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                              float skip_below, const int* row_piv, const int* tile_rp, const float* tile_alpha,
-                              const float* piv, const float* pang, int P, float margin, sed_stream_t stream);
-/* Farthest-point pivot rows for the row order of the block-sparse schedules: greedy k-centre on the unit sphere among rows
+                          void* workspace, size_t workspace_bytes, const sed_ms_options_t* opt, sed_stream_t stream);
+/* Farthest-point pivot rows for the row order of the block-sparse schedule: greedy k-centre on the unit sphere among rows
  * 0, stride, 2 stride, ... (<= 4096 candidates per cloud), all P steps in one launch. picks [B,P] row indices (the first is
  * row 0), picked [B,P,128] those rows. d = 128. */
 int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, int* picks, float* picked,
                        sed_stream_t stream);
-/* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel). X: unit rows
- * sorted so that 32-row tiles are cluster-pure (any order is correct; the order decides how much is skipped). Every tile t
+/* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel): identical
+ * arithmetic, except that 32 x 32 (keys x queries) blocks in which every kernel weight is provably <= e^skip_below are skipped;
+ * with skip_below = -30 every dropped weight is <= 9.4e-14, so a row sum (>= 1, the self weight) changes by <= N e^-30
+ * relative: <= 1e-9 at N = 10 000, 60 x below fp32 resolution. X: unit rows sorted so that 32-row tiles are cluster-pure (any
+ * order is correct; the order decides how much is skipped). Every tile t
  * has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
  * split) -- stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128], nref = sed_ms_iterate_bounds_f16_refs(N),
  * unused rows zero; tile_cosalpha [B, nref]: the smallest dot product of a row of the group with its reference. Every
@@ -130,29 +130,14 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
  * angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for all its queries and both references. workspace: stage
  * images of rows and references; stats: NULL or 5 device uint64 counters that are ADDED to (stage visits of workgroups,
  * first products of waves, second products of waves, stages x iterations per wave = the dense count, mask / list
- * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.03 rad). Clouds whose rows
- * are not unit vectors run the exact dense fp32 kernel. N <= 16 384. */
+ * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.005 rad). weight_digits: as in
+ * sed_ms_options_t. Clouds whose rows are not unit vectors run the exact dense fp32 kernel. N <= 16 384. */
 int sed_ms_iterate_bounds_f16_refs(int N);
-/* 1 (default): block-sparse kernel on the four-plane stage images of the dense kernels (37 KiB per 32-key stage, 3 LDS
- * buffers); 0: row-major-only stage images (17 KiB per stage, transpose reads, 6 buffers; measured 8 % slower). */
-int sed_ms_set_f16_sparse_config(int cfg);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
 int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   float skip_below, const float* tile_ref, const float* tile_cosalpha, float margin,
-                                  void* workspace, size_t workspace_bytes, void* stats, sed_stream_t stream);
-/* d = 128 has several schedules that differ only in the order tile contributions are summed: batched (one workgroup =
- * 128 queries, all keys, all iterations), split-key (32 queries, keys split over 8 waves), key-chunked (workspace
- * variant above), and split-fp16 (ms_iterate_f16.hip: the two fp32 products evaluated as 3 fp16 MFMAs each on round-to-
- * nearest (h, l) splits of the fp32 operands -- dropped terms <= 3 * 2^-24 relative, fp32 accumulation -- needs the
- * workspace; clouds whose rows are not unit vectors fall back to the fp32 kernel on the device). 0 = choose by size
- * (default: split-fp16 whenever the workspace is given; its key-chunked form, one launch pair per iteration, when few
- * clouds would leave CUs idle), 1 = batched, 2 = split-key, 3 = key-chunked, 4 = split-fp16, 5 = key-chunked split-fp16
- * (tests, measurements). */
-int sed_ms_set_variant(int variant);
-/* split-fp16 schedule: 0 = pipelined kernel (32-key stages, three LDS buffers, operand ring, wave groups half a block out
- * of phase; default); 1 = the same with the groups in phase; 2 / 3 = first version, 64-key stages + one 8-wave workgroup
- * per CU / 32-key stages + two 4-wave workgroups per CU (measurements). Changes sed_ms_iterate_workspace_bytes. */
-int sed_ms_set_f16_config(int cfg);
+                                  void* workspace, size_t workspace_bytes, void* stats, int weight_digits,
+                                  sed_stream_t stream);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
  * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */
@@ -167,12 +152,11 @@ int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, co
  * -> ysel [B,N,Cout] (max_k y where gamma >= 0 else min_k y), stats [B][G][2] = (mean, rstd).
  * src/PointNet.py:150-171 + src/SEDNet.py:37-45 + :82 */
 size_t sed_edgeconv_partials_bytes(int B, int N, int Cout);
-/* Products of the inference forward of the 64-channel layers (sed_edgeconv_fwd_f32): on = 1 (default) three-way bf16 splits of
- * both operands on the bf16 matrix pipe (six MFMAs per 16 channels, fp32-equivalent), 0 = fp32-input MFMA chains. */
-int sed_edgeconv_set_split(int on);
+/* products (inference forward of the 64-channel layers): 0 = three-way bf16 splits of both operands on the bf16 matrix pipe
+ * (default; six MFMAs per 16 channels, fp32-equivalent), 1 = fp32-input MFMA chains. */
 int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                          const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
-                         void* partials, size_t partials_bytes, sed_stream_t stream);
+                         void* partials, size_t partials_bytes, int products, sed_stream_t stream);
 /* Training forward of the same layer: additionally records jsel [B,N,Cout] u8 = the neighbour slot whose value was
  * selected by the max over k (first one on ties; k <= 255); torch.max's backward routes the gradient there. */
 int sed_edgeconv_fwd_train_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,

@@ -287,10 +287,8 @@ KWs kcarve(void* ws, int B, int N) {
     return w;
 }
 
-int g_kth_quarter = 1;            // sweep 1 on every fourth key tile for N >= 8192 (sed_ms_kth_set_sampling)
-
 template <int NT>
-void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, hipStream_t s) {
+void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, bool quarter, hipStream_t s) {
     const dim3 grid((N + 127) / 128, B);
     constexpr bool F16 = NT == 2 || NT == 4;
     if (F16) {
@@ -299,7 +297,7 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
         split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
         X = (const float*)w.img;
     }
-    if (N >= 8192 && K <= KMAX && g_kth_quarter)      // (larger K: 128 bucket values saturate, T loosens, the lists overflow)
+    if (N >= 8192 && K <= KMAX && quarter)      // (larger K: 128 bucket values saturate, T loosens, the lists overflow)
         ms_kth_sweep_kernel<NT, 1, F16, false, 4><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     else
         ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
@@ -309,13 +307,6 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
 }
 
 }  // namespace
-
-// sweep-1 sampling of large clouds: 4 = every fourth key tile (default), 2 = every other one
-extern "C" int sed_ms_kth_set_sampling(int stride) {
-    if (stride != 2 && stride != 4) return SED_EINVAL;
-    g_kth_quarter = stride == 4;
-    return SED_OK;
-}
 
 // largest K the fused path takes for clouds of N points
 extern "C" int sed_ms_kth_fused_max_k(int N) { return N >= 4096 ? KMAX_SAMPLED : KMAX; }
@@ -330,20 +321,23 @@ extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
 // X [B,N,d] unit rows, d in {32, 64, 96, 128} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
 // over j, bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32. overflow [B] (device ints, zeroed here): overflow[b]
 // becomes 1 if a candidate list of cloud b overflowed (or its threshold fell short): kth[b] is then invalid and the caller
-// must use the materialised path for that cloud.
+// must use the materialised path for that cloud. sampling: first sweep of clouds of >= 8192 points on every fourth key tile
+// (0 = default, or 4) or on every other one (2); results identical (the second sweep verifies the threshold).
 extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                                    int* overflow, hipStream_t stream) {
+                                    int* overflow, int sampling, hipStream_t stream) {
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
+    if (sampling != 0 && sampling != 2 && sampling != 4) return SED_EINVAL;
+    const bool quarter = sampling != 2;
     if (d % 32 != 0 || d < 32 || d > 128 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
     hipError_t e = hipMemsetAsync(overflow, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     switch (d / 32) {
-        case 1: launch_kth<1>(B, X, w, N, K, overflow, stream); break;
-        case 2: launch_kth<2>(B, X, w, N, K, overflow, stream); break;
-        case 3: launch_kth<3>(B, X, w, N, K, overflow, stream); break;
-        default: launch_kth<4>(B, X, w, N, K, overflow, stream); break;
+        case 1: launch_kth<1>(B, X, w, N, K, overflow, quarter, stream); break;
+        case 2: launch_kth<2>(B, X, w, N, K, overflow, quarter, stream); break;
+        case 3: launch_kth<3>(B, X, w, N, K, overflow, quarter, stream); break;
+        default: launch_kth<4>(B, X, w, N, K, overflow, quarter, stream); break;
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;

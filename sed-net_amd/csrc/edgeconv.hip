@@ -270,13 +270,6 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, in
 
 }  // namespace
 
-// inference products of the 64-channel layers: 1 = three-way bf16 splits on the bf16 matrix pipe (default), 0 = fp32-input MFMA
-static int g_edgeconv_x3 = 1;
-extern "C" int sed_edgeconv_set_split(int on) {
-    g_edgeconv_x3 = on ? 1 : 0;
-    return SED_OK;
-}
-
 extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
     return (size_t)B * ((N + 127) / 128) * (Cout / 32) * 2 * sizeof(double);
 }
@@ -286,7 +279,8 @@ extern "C" size_t sed_edgeconv_partials_bytes(int B, int N, int Cout) {
 // GroupNorm gamma >= 0 else -1. Outputs: ysel [B,N,Cout], stats [B][G][2] = (mean, rstd) over all N*k*(Cout/G).
 static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx, const int* idx,
                         const float* W1t, const float* W2t, const float* sgn, float eps, float* ysel, float* stats,
-                        void* partials, size_t partials_bytes, uint8_t* jsel, hipStream_t stream, bool bf16 = false) {
+                        void* partials, size_t partials_bytes, uint8_t* jsel, hipStream_t stream, bool bf16 = false,
+                        bool x3 = true) {
     if (B <= 0 || N <= 0 || k <= 0 || !x || !idx || !W1t || !W2t || !sgn || !ysel || !stats || !partials)
         return SED_EINVAL;
     if (Cout % 64 != 0 || G <= 0 || (Cout / G) % 32 != 0 || ldx < C) return SED_EUNSUPPORTED;
@@ -307,7 +301,7 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
             edgeconv_kernel<32, true, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
         else if (jsel)
             edgeconv_kernel<32, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
-        else if (g_edgeconv_x3) {
+        else if (x3) {
             const size_t sm3 = (size_t)2 * 3 * 64 * (64 + 8) * sizeof(__bf16) + 16 * sizeof(double) + 64;
             edgeconv_kernel<32, false, false, true><<<grid, block, sm3, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N,
                                                                                   nullptr);
@@ -325,9 +319,12 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
 extern "C" int sed_edgeconv_fwd_f32(int B, int N, int C, int Cout, int k, int G, const float* x, int ldx,
                                     const int* idx, const float* W1t, const float* W2t, const float* sgn, float eps,
                                     float* ysel, float* stats, void* partials, size_t partials_bytes,
-                                    hipStream_t stream) {
+                                    int products, hipStream_t stream) {
+    // products (64-channel layers): 0 = three-way bf16 splits on the bf16 matrix pipe (default, fp32-equivalent),
+    // 1 = fp32-input MFMA chains
+    if (products != 0 && products != 1) return SED_EINVAL;
     return edgeconv_fwd(B, N, C, Cout, k, G, x, ldx, idx, W1t, W2t, sgn, eps, ysel, stats, partials, partials_bytes,
-                        nullptr, stream);
+                        nullptr, stream, false, products == 0);
 }
 
 // Training forward: same outputs plus jsel [B,N,Cout] u8 = neighbour slot of the selected extreme (k <= 255).

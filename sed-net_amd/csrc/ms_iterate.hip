@@ -824,8 +824,6 @@ int ms_plan(int B, int N, int d, bool have_ws, bool have_f16, int forced) {
     return ck < cb ? MS_SPLITK : MS_BATCHED;
 }
 
-int g_ms_variant = 0;      // 0 = choose by size, 1 = batched fp32, 2 = split-key fp32, 3 = key-chunked fp32, 4 = split-fp16
-
 }  // namespace
 
 // ms_iterate_f16.hip
@@ -833,15 +831,15 @@ size_t ms_f16_chunked_workspace_bytes(int B, int N);
 int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
                                                           int, int*, hipStream_t),
-                          hipStream_t stream);
+                          int digits, hipStream_t stream);
 size_t ms_f16_workspace_bytes(int B, int N);
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
-                  int** flags_out, hipStream_t stream);
+                  int** flags_out, int digits, hipStream_t stream);
 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
-                         float margin, unsigned long long* stats, hipStream_t stream);
+                         float margin, unsigned long long* stats, int digits, hipStream_t stream);
 
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
                              int N, int* lowq, hipStream_t stream) {
@@ -850,22 +848,24 @@ static int ms_combine_launch(const float* partO, const float* partS, const float
     return SED_OK;
 }
 
-extern "C" int sed_ms_set_variant(int variant) {
-    if (variant < 0 || variant > 5) return SED_EINVAL;
-    g_ms_variant = variant;
-    return SED_OK;
+// Per-call options (include/sednet_hip.h: sed_ms_options_t); NULL = defaults. The library keeps no state between calls.
+struct sed_ms_options { int schedule; int weight_digits; };
+static int opt_schedule(const sed_ms_options* o) { return o ? o->schedule : 0; }
+static int opt_digits(const sed_ms_options* o) { return (o && o->weight_digits == 2) ? 2 : 1; }
+static bool opt_valid(const sed_ms_options* o) {
+    return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2);
 }
 
 // which schedule sed_ms_iterate_ws_f32 runs for this shape when given the workspace it asks for:
-// 1 batched fp32, 2 split-key fp32, 3 key-chunked fp32, 4 split-fp16 (0 = unsupported shape)
-extern "C" int sed_ms_iterate_plan(int B, int N, int d) {
-    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
-    return ms_plan(B, N, d, true, true, g_ms_variant);
+// 1 batched fp32, 2 split-key fp32, 3 key-chunked fp32, 4 split-fp16, 5 key-chunked split-fp16 (0 = unsupported shape / options)
+extern "C" int sed_ms_iterate_plan(int B, int N, int d, const sed_ms_options* opt) {
+    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0 || !opt_valid(opt)) return 0;
+    return ms_plan(B, N, d, true, true, opt_schedule(opt));
 }
 
-extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
-    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0) return 0;
-    const int plan = ms_plan(B, N, d, true, true, g_ms_variant);
+extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options* opt) {
+    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0 || !opt_valid(opt)) return 0;
+    const int plan = ms_plan(B, N, d, true, true, opt_schedule(opt));
     if (plan == MS_F16) return ms_f16_workspace_bytes(B, N);
     if (plan == MS_F16_CHUNKED) return ms_f16_chunked_workspace_bytes(B, N);
     if (plan != MS_CHUNKED) return 0;
@@ -875,28 +875,29 @@ extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d) {
 // Same contract as sed_ms_iterate_f32 plus a caller-owned workspace (sed_ms_iterate_workspace_bytes): with it, small
 // batches at d = 128 run the key-chunked variant (one launch pair per iteration) that keeps all CUs busy.
 extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                                     void* workspace, size_t workspace_bytes, hipStream_t stream);
+                                     void* workspace, size_t workspace_bytes, const sed_ms_options* opt, hipStream_t stream);
 
 extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   hipStream_t stream) {
-    return sed_ms_iterate_ws_f32(B, N, d, iters, bw, X, newX, nullptr, 0, stream);
+    return sed_ms_iterate_ws_f32(B, N, d, iters, bw, X, newX, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX) return SED_EINVAL;
+                                     void* workspace, size_t workspace_bytes, const sed_ms_options* opt, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !opt_valid(opt)) return SED_EINVAL;
+    const int forced = opt_schedule(opt), digits = opt_digits(opt);
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     dim3 grid((N + 127) / 128, B), block(256);
     const int S = ms_chunks(N);
     const size_t need = (size_t)B * N * S * (d + 1) * sizeof(float);
     const bool have_f16 = iters > 0 && workspace && d == 128 && workspace_bytes >= ms_f16_workspace_bytes(B, N);
-    int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, g_ms_variant);
+    int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, forced);
     if (plan == MS_F16_CHUNKED && workspace_bytes < ms_f16_chunked_workspace_bytes(B, N)) plan = MS_F16;
     if (plan == MS_F16 || plan == MS_F16_CHUNKED) {
         int* flags = nullptr;
-        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, stream)
+        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, digits, stream)
                                       : ms_f16_chunked_launch(B, N, iters, bw, X, newX, workspace, &flags,
-                                                              ms_combine_launch, stream);
+                                                              ms_combine_launch, digits, stream);
         if (rc != SED_OK) return rc;
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud
@@ -975,27 +976,6 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     return SED_OK;
 }
 
-// Opt-in block-sparse schedule of the batched d = 128 kernel: identical arithmetic, except that a wave skips a 32 x 32
-// (keys x queries) block whose exponent arguments are all below `skip_below` (< 0; -30 drops weights <= 9.4e-14, a
-// relative perturbation of the row sums <= N e^-30). The caller orders the rows so that blocks are cluster-pure
-// (sednet_hip.ops.ms_iterate_sparse sorts by nearest pivot and restores the order). src/mean_shift.py:45-79.
-extern "C" int sed_ms_iterate_sparse_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
-                                         float skip_below, hipStream_t stream) {
-    if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f)) return SED_EINVAL;
-    if (d != 128) return SED_EUNSUPPORTED;
-    constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    ms_iterate_d128_kernel<true><<<dim3((N + 127) / 128, B), 256, sm, stream>>>(X, newX, bw, N, iters, skip_below);
-    SED_LAUNCH_CHECK();
-    return SED_OK;
-}
-
 // ---- block-sparse split-fp16 schedule (ms_iterate_f16.hip: ms_iterate_d128_f16s_kernel) ------------------------------
 // X [B,N,128]: unit rows sorted so that 32-row tiles are cluster-pure (any order is CORRECT; the order decides how much can
 // be skipped); every tile t has two unit reference vectors (normalised means of two groups of its rows -- the rows before
@@ -1016,15 +996,15 @@ extern "C" size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N) {
 extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X,
                                              float* newX, float skip_below, const float* tile_ref,
                                              const float* tile_cosalpha, float margin, void* workspace,
-                                             size_t workspace_bytes, void* stats, hipStream_t stream) {
+                                             size_t workspace_bytes, void* stats, int weight_digits, hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !tile_ref || !tile_cosalpha ||
-        margin < 0.f || !workspace)
+        margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2)
         return SED_EINVAL;
     if (d != 128) return SED_EUNSUPPORTED;
     if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
     int* flags = nullptr;
     const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
-                                        margin, (unsigned long long*)stats, stream);
+                                        margin, (unsigned long long*)stats, weight_digits == 2 ? 2 : 1, stream);
     if (rc != SED_OK) return rc;
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
     static bool attr_fb = false;

@@ -16,6 +16,14 @@ LIB_PATH = os.environ.get("SEDHIP_LIB") or os.path.join(_HERE, "libsedhip.so")  
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 P = c_void_p  # every device pointer / stream travels as void*
 
+
+class MsOptions(ctypes.Structure):
+    """sed_ms_options_t (include/sednet_hip.h): per-call options of the mean-shift iteration entry points."""
+    _fields_ = [("schedule", c_int), ("weight_digits", c_int)]
+
+
+OPT = ctypes.POINTER(MsOptions)
+
 # name -> (restype, argtypes); mirrors include/sednet_hip.h one to one
 SIGNATURES = {
     "sed_abi_version": (c_int, []),
@@ -34,28 +42,21 @@ SIGNATURES = {
     "sed_ms_bandwidth_finalize_f32": (c_int, [c_int, c_int, c_float, P, P, P]),
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_kth_fused_max_k": (c_int, [c_int]),
-    "sed_ms_kth_set_sampling": (c_int, [c_int]),
     "sed_ms_kth_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
-    "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "sed_ms_iterate_plan": (c_int, [c_int, c_int, c_int]),
-    "sed_ms_iterate_ws_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
-    "sed_ms_iterate_sparse_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P]),
-    "sed_ms_iterate_bounds_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, P, P, P, c_int, c_float, P]),
+    "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, c_int, P]),
+    "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int, OPT]),
+    "sed_ms_iterate_plan": (c_int, [c_int, c_int, c_int, OPT]),
+    "sed_ms_iterate_ws_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, OPT, P]),
     "sed_fps_pivots_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "sed_ms_set_f16_sparse_config": (c_int, [c_int]),
     "sed_ms_iterate_bounds_f16_refs": (c_int, [c_int]),
     "sed_ms_iterate_bounds_f16_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_iterate_bounds_f16_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_float, P, P, c_float, P, c_size_t, P,
-                                              P]),
-    "sed_ms_set_variant": (c_int, [c_int]),
-    "sed_ms_set_f16_config": (c_int, [c_int]),
+                                              c_int, P]),
     "sed_ms_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_ms_nms_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sed_edgeconv_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "sed_edgeconv_set_split": (c_int, [c_int]),
     "sed_edgeconv_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P, P,
-                                     P, c_size_t, P]),
+                                     P, c_size_t, c_int, P]),
     "sed_edgeconv_fwd_train_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,
                                            P, P, P, c_size_t, P]),
     "sed_gn_bwd_partials_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -151,6 +151,7 @@ def knn_points_normals(x6, k, W=1.0):
 # ---------------------------------------------------------------------------------------------------
 
 KTH_FUSED_MIN_BLOCKS = 0        # the fused path wins at every batch size since its sweeps run split-fp16 (round 2)
+KTH_SAMPLING = 0                # first bandwidth sweep of clouds of >= 8192 points: 0 / 4 = every fourth key tile, 2 = every other
 
 
 def ms_bandwidth(X, K, min_bw=0.003):
@@ -168,7 +169,8 @@ def ms_bandwidth(X, K, min_bw=0.003):
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
         flag = torch.empty((B,), dtype=torch.int32, device=X.device)
-        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), stream()), "ms_kth_fused")
+        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), int(KTH_SAMPLING), stream()),
+              "ms_kth_fused")
         todo = torch.nonzero(flag.cpu()).squeeze(1)         # one small D->H copy
         FUSED_STATS["fused"] += B - todo.numel()
         FUSED_STATS["fallback"] += todo.numel()
@@ -197,21 +199,35 @@ MS_SPARSE = "auto"
 MS_SPARSE_SKIP = -30.0
 MS_SPARSE_MAX_NEAR = 0.3
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
+# Options of the iteration kernels. They are the WRAPPER's state, handed to the library with every call (sed_ms_options_t);
+# libsedhip.so itself keeps none. CONFIG_EPOCH counts changes of any kernel-selection switch of this module, so that
+# captured HIP graphs (pipeline.py) can be keyed on it.
 _MS_VARIANT = "auto"
 _MS_WEIGHT_DIGITS = 1
+CONFIG_EPOCH = 0
+_MS_SCHEDULES = {"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16c": 5}
+
+
+def config_changed():
+    global CONFIG_EPOCH
+    CONFIG_EPOCH += 1
+
+
+def _ms_options():
+    return _lib.MsOptions(_MS_SCHEDULES[_MS_VARIANT], _MS_WEIGHT_DIGITS)
 
 
 def ms_set_weight_digits(digits):
     """fp16 digits of the kernel weights in the split-fp16 mean-shift kernels' second product: 1 (default; fp16 heads only,
     consistently in numerator and row sum: 5 MFMAs per block pair, rows within ~5e-7 of the exact fp32 kernel per iteration) or
-    2 ((h, l) pairs, 6 MFMAs, fp32-equivalent: ~1e-7; 12 % slower). Applies to the automatic schedule choice, dense and
-    block-sparse."""
+    2 ((h, l) pairs, 6 MFMAs, fp32-equivalent: ~1e-7; 12 % slower). Applies to the dense and the block-sparse schedule."""
     global _MS_WEIGHT_DIGITS
     if digits not in (1, 2):
         raise ValueError("digits must be 1 or 2")
     _MS_WEIGHT_DIGITS = digits
-    check(lib.sed_ms_set_f16_sparse_config(3 - digits), "ms_set_f16_sparse_config")
-    ms_set_variant(_MS_VARIANT)
+    config_changed()
+
+
 _PROBE_IDX = {}
 
 
@@ -277,20 +293,19 @@ def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
     return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P)), skey // P
 
 
-def ms_sparse_prepare(X, n_pivots=64, bounds=True, f16=True):
-    """Sorted rows + the geometric side tables of the block-sparse kernels (functions of X alone). -> dict.
-    f16 kernel: per 32-row tile its normalised mean and the smallest dot product of a row with it; fp32 bounds kernel:
-    the pivot tables of sed_ms_iterate_bounds_f32."""
+def ms_sparse_prepare(X, n_pivots=64):
+    """Sorted rows + the geometric side tables of the block-sparse kernel (functions of X alone): per 32-row tile two
+    normalised group means and the smallest dot product of a row of each group with its mean. -> dict."""
     B, N, D = X.shape
+    if N > 16384 or D != 128:
+        raise RuntimeError("block-sparse mean-shift schedule: d = 128 and N <= 16384 only")
     order, piv, sdots, comp = ms_pivot_order(X, n_pivots)
     gidx = order.unsqueeze(-1).expand(B, N, D)
     Xs = torch.gather(X, 1, gidx).contiguous()
-    prep = {"gidx": gidx, "Xs": Xs, "bounds": bounds and N <= 16384, "f16": f16}
-    if not prep["bounds"]:
-        return prep
+    prep = {"gidx": gidx, "Xs": Xs}
     ntile = (N + 31) // 32
     pad = ntile * 32 - N
-    if f16:
+    if True:
         # two references per tile: the rows of the tile's first super-group and the rest (a tile inside one cluster: its two
         # halves), so that the tile at the border between two clusters is covered by two narrow caps instead of a wide one
         if pad:                                                               # pad with copies of the last row
@@ -316,16 +331,6 @@ def ms_sparse_prepare(X, n_pivots=64, bounds=True, f16=True):
             ref[:, rho] = m
             cosalpha[:, rho] = torch.where(g, dots, torch.ones_like(dots)).min(2)[0]
         prep.update(ref=ref, cosalpha=cosalpha)
-    else:
-        P = piv.shape[1]
-        sd = sdots.clamp(-1.0, 1.0)
-        if pad:
-            sd = torch.nn.functional.pad(sd, (0, 0, 0, pad), value=1.0)
-        worst = sd.view(B, ntile, 32, P).min(2)[0]                           # per tile and pivot: its farthest row
-        best, rp = worst.max(2)                                               # reference pivot = tightest cap over the tile
-        prep.update(P=P, piv=piv, alpha=torch.acos(best).contiguous(), rp=rp.int().contiguous(),
-                    pang=torch.acos(torch.bmm(piv, piv.transpose(1, 2)).clamp(-1.0, 1.0)).contiguous(),
-                    rowp=sdots.argmax(2).int().contiguous())                  # nearest pivot of every (sorted) row
     return prep
 
 
@@ -336,35 +341,25 @@ def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if prep["bounds"] and prep["f16"]:
-        nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
-        ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
-        check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                                ptr(prep["ref"]), ptr(prep["cosalpha"]), float(margin), ptr(ws), nws,
-                                                ptr(stats) if stats is not None else None, stream()),
-              "ms_iterate_bounds_f16")
-    elif prep["bounds"]:
-        check(lib.sed_ms_iterate_bounds_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                            ptr(prep["rowp"]), ptr(prep["rp"]), ptr(prep["alpha"]), ptr(prep["piv"]),
-                                            ptr(prep["pang"]), prep["P"], float(margin), stream()), "ms_iterate_bounds")
-    else:
-        check(lib.sed_ms_iterate_sparse_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
-                                            stream()), "ms_iterate_sparse")
+    nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
+    check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
+                                            ptr(prep["ref"]), ptr(prep["cosalpha"]), float(margin), ptr(ws), nws,
+                                            ptr(stats) if stats is not None else None, _MS_WEIGHT_DIGITS, stream()),
+          "ms_iterate_bounds_f16")
     if TIMERS is not None:
         ev1.record()
         TIMERS.append(("ms_iterate_sparse", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
     return torch.empty_like(outs).scatter_(1, prep["gidx"], outs)
 
 
-def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, bounds=True, margin=2e-3, f16=True, stats=None):
+def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, margin=2e-3, stats=None):
     """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
     are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
-    caller's row order. bounds=True (sed_ms_iterate_bounds_f32) skips blocks before the first product using angular
-    bounds against the pivots; bounds=False (sed_ms_iterate_sparse_f32) decides after the first product. d = 128 only.
-    f16 (with bounds): products on the fp16 matrix pipe and bounds from the exact angle of every query to every tile's
-    mean (split-fp16, sed_ms_iterate_bounds_f16_f32); stats: optional int64 [5] device tensor the kernel adds its visit
-    counts to."""
-    return ms_sparse_run(ms_sparse_prepare(X, n_pivots, bounds, f16), bw, iters, skip_below, margin, stats)
+    caller's row order. Products on the fp16 matrix pipe, bounds from the exact angle of every query to every tile's two
+    group means (sed_ms_iterate_bounds_f16_f32). d = 128 only. stats: optional int64 [5] device tensor the kernel adds its
+    visit counts to."""
+    return ms_sparse_run(ms_sparse_prepare(X, n_pivots), bw, iters, skip_below, margin, stats)
 
 
 def ms_iterate(X, bw, iters):
@@ -404,33 +399,29 @@ def _ms_iterate_dense(X, bw, iters):
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    nws = lib.sed_ms_iterate_workspace_bytes(B, N, D)      # split-fp16 stage images (d = 128) / key-chunked partials
+    opt = _ms_options()
+    nws = lib.sed_ms_iterate_workspace_bytes(B, N, D, opt)      # split-fp16 stage images (d = 128) / key-chunked partials
     ws = torch.empty((nws,), dtype=torch.uint8, device=X.device) if nws else None
     check(lib.sed_ms_iterate_ws_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), ptr(ws) if nws else None, nws,
-                                    stream()), "ms_iterate")
+                                    opt, stream()), "ms_iterate")
     if TIMERS is not None:
         ev1.record()
-        plan = lib.sed_ms_iterate_plan(B, N, D) if nws else 1
+        plan = lib.sed_ms_iterate_plan(B, N, D, opt) if nws else 1
         TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters),
                                                 "schedule": "split-fp16" if plan in (4, 5) else "fp32"}))
     return out
 
 
 def ms_set_variant(variant):
-    """Force the d = 128 mean-shift schedule: "auto" (by size), the fp32 schedules "batched", "splitk", "chunked", or
-    "f16" (split-fp16 MFMA emulation, software-pipelined kernel; "f16c" = its key-chunked form for few clouds per call,
-    "f16g" / "f16i" = the earlier pipelined kernel with wave groups half a block out of phase / in phase, "f16v1" / "f16b" =
-    the first, unpipelined version with 64-key / 32-key stages). "f16" / "f16c" feed the weights into the second product and the
-    row sum as their fp16 heads only (5 MFMAs per block pair); "f16" reads row-major-only stage images (transpose reads for the
-    second product), "f16q" / "f16qc" are the same arithmetic on four-plane images (one-launch / key-chunked form); "f16x" / "f16xc" / "f16r" = the
-    four-plane / key-chunked / row-major kernels with (h, l) weights (6 MFMAs), like all the earlier versions. "f16e" = the
-    experimental form of "f16" whose x_l correction term runs on the fp8 matrix pipe (4.5 MFMAs per block pair; not faster)."""
+    """Force the d = 128 mean-shift schedule (a forced schedule also switches the per-cloud block-sparse selection off):
+    "auto" (by size), the exact fp32 schedules "batched", "splitk", "chunked", or the split-fp16 kernel in its one-launch
+    form "f16" / its key-chunked form for few clouds per call "f16c" (ms_iterate_d128_f16r_kernel). The number of weight
+    digits is a separate switch (ms_set_weight_digits)."""
     global _MS_VARIANT
-    _MS_VARIANT = variant               # a forced dense schedule also switches the block-sparse selection off
-    check(lib.sed_ms_set_f16_config({"f16i": 1, "f16v1": 2, "f16b": 3, "f16g": 4, "f16r": 5, "f16x": 6, "f16xc": 6, "f16q": 7, "f16qc": 7, "f16e": 8}.get(
-        variant, 0 if _MS_WEIGHT_DIGITS == 1 else 6)), "ms_set_f16_config")
-    check(lib.sed_ms_set_variant({"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16c": 5, "f16xc": 5, "f16qc": 5}.get(variant, 4)),
-          "ms_set_variant")
+    if variant not in _MS_SCHEDULES:
+        raise ValueError(f"unknown mean-shift schedule {variant!r} (one of {sorted(_MS_SCHEDULES)})")
+    _MS_VARIANT = variant
+    config_changed()
 
 
 def ms_nms(centres, X, bw):
@@ -460,6 +451,9 @@ def _bytes(n, device):
     return torch.empty((max(int(n), 8),), dtype=torch.uint8, device=device)
 
 
+EDGECONV_SPLIT = True     # inference products of the 64-channel EdgeConv layers: three-way bf16 splits (False: fp32-input MFMA)
+
+
 def edgeconv(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
     """x [B,N,ldx] point-major, idx [B,N,k] i32 -> (ysel [B,N,Cout], stats [B,G,2]); see edgeconv.hip."""
     B, N, ldx = x.shape
@@ -470,7 +464,8 @@ def edgeconv(x, C, idx, W1t, W2t, sgn, G, eps=1e-5):
     nb = lib.sed_edgeconv_partials_bytes(B, N, Cout)
     part = _bytes(nb, x.device)
     check(lib.sed_edgeconv_fwd_f32(B, N, C, Cout, k, G, ptr(x), ldx, ptr(idx), ptr(W1t), ptr(W2t), ptr(sgn),
-                                   float(eps), ptr(ysel), ptr(stats), ptr(part), nb, stream()), "edgeconv_fwd")
+                                   float(eps), ptr(ysel), ptr(stats), ptr(part), nb, 0 if EDGECONV_SPLIT else 1, stream()),
+          "edgeconv_fwd")
     return ysel, stats
 
 

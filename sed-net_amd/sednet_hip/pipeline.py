@@ -62,6 +62,8 @@ class SegmentationPipeline:
                 import warnings
                 warnings.warn(f"SegmentationPipeline: HIP-graph capture of the forwards failed ({e!r}); using the two-stream order")
                 self._graph_ok = False
+                self._graphs = None          # nothing half-captured is kept; the forked side stream is replaced by a fresh one
+                self._side = None
         return self._forwards_plain(x6, ev)
 
     def _forwards_plain(self, x6, ev=None):
@@ -114,7 +116,9 @@ class SegmentationPipeline:
         # (a graph bakes in the addresses of the models' cached weight images: keyed by the parameters' identity / version, and the
         # entry keeps those caches alive)
         # (SEDNet._signature covers the encoder's parameters too: it walks self.parameters())
-        key = (tuple(x6.shape), self.model_type._signature(), self.model_inst._signature())
+        # ... and every kernel-selection switch of the forwards that the capture bakes in: toggling one replays nothing stale
+        key = (tuple(x6.shape), self.model_type._signature(), self.model_inst._signature(),
+               ops.POINTWISE_SPLIT, ops.EDGECONV_SPLIT, ops.FUSED_KNN, ops.TRAIN_BF16)
         ent = self._graphs.get(key) if self._graphs is not None else None
         if ent is None:
             if self._graphs is None:

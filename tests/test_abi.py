@@ -59,6 +59,28 @@ def test_identity_and_argument_validation(lib):
     assert lib.sed_ms_nms_workspace_bytes(2, 100) >= 2 * 100 * 5 * 4 + 2 * 4 + 2 * 2 * 100 * (128 + 1) * 4   # + split-fp16 images
 
 
+def test_library_keeps_no_mutable_global_state(lib):
+    """"re-entrant; no global state". No process-wide setter is exported, and no kernel source keeps a
+    mutable global that a call could leave behind (function-local `static bool attr` flags only remember that a kernel's
+    dynamic-LDS limit has been raised -- idempotent, not behaviour)."""
+    assert not [n for n in declared() if "_set_" in n]
+    bad = []
+    csrc = os.path.join(ROOT, "sed-net_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if re.match(r"^(static\s+)?(int|float|bool|unsigned|size_t)\s+g_\w+", line):
+                    bad.append(f"{f}:{i}: {line.strip()}")
+    assert not bad, bad
+    # options travel per call: a NULL options pointer means defaults, an out-of-range schedule is rejected
+    from sednet_hip import _lib
+    assert _lib.lib.sed_ms_iterate_plan(64, 10000, 128, None) == 4
+    assert _lib.lib.sed_ms_iterate_plan(1, 10000, 128, None) == 5
+    assert _lib.lib.sed_ms_iterate_plan(64, 10000, 128, _lib.MsOptions(1, 0)) == 1
+    assert _lib.lib.sed_ms_iterate_plan(64, 10000, 128, _lib.MsOptions(9, 0)) == 0
+    assert _lib.lib.sed_ms_iterate_workspace_bytes(64, 10000, 128, _lib.MsOptions(0, 3)) == 0
+
+
 def test_product_path_refuses_cpu_tensors():
     """no CPU fallback: host tensors raise instead of silently computing elsewhere."""
     import torch

@@ -13,7 +13,7 @@ for Cout in (64, 128):
     sgn = torch.where(torch.randn(Cout, generator=g) >= 0, 1.0, -1.0).cuda()
     res = {}
     for on in (0, 1, 0, 1):
-        lib.sed_edgeconv_set_split(on)
+        ops.EDGECONV_SPLIT = bool(on)
         ops.edgeconv(x, 64, idx, W1t, W2t, sgn, 2); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -23,4 +23,4 @@ for Cout in (64, 128):
         print(f"Cout {Cout} split {on}: {e0.elapsed_time(e1) / 3:.3f} ms")
     d = (res[0][0] - res[1][0]).abs().max().item(); sc = res[0][0].abs().max().item()
     print(f"  max |y_fp32 - y_split| {d:.3e} (scale {sc:.2f}); stats diff {(res[0][1] - res[1][1]).abs().max().item():.3e}")
-lib.sed_edgeconv_set_split(1)
+ops.EDGECONV_SPLIT = True

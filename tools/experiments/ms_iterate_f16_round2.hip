@@ -1,0 +1,2619 @@
+// Mean-shift iterations (d = 128) on the fp16 matrix pipe with fp32-equivalent arithmetic: split-fp16 emulation.
+//
+// Same mathematics as ms_iterate.hip (/root/reference/src/mean_shift.py:56-77, guard.py:7-9); what changes is how the
+// two fp32 products  S = Q X^T  and  O = P X  are evaluated.  v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate
+// (157 TFLOP/s); v_mfma_f32_32x32x16_f16 is 16 x faster.  Every fp32 operand v is split (round to nearest) into
+//     v * 2^s = h + l + e,   h = fp16(v 2^s),  l = fp16(v 2^s - h),  |e| <= 2^-24 |v 2^s|      (two 11-bit signed digits)
+// and a product a.b is evaluated as  l_a h_b + h_a l_b + h_a h_b : three fp16 MFMAs (products of two fp16 values are
+// exact in fp32, accumulation is the MFMA's fp32 accumulator).  What is dropped -- l_a l_b and the e terms -- is
+// <= 3 * 2^-24 relative to |a||b| per product, i.e. the size of ONE fp32 rounding, whereas the fp32 fma chain it replaces
+// rounds 128 (S) / 10 000 (O) times.  3 fp16 MFMAs instead of 16 fp32-rate units: 5.3 x less matrix time.
+// Scales: X and Q by 2^11 (unit rows: |x| <= 1 -> |h| <= 2048, l stays in fp16's normal range for |x| >= 2^-14),
+// P by 2^14 (weights <= 1; anything below 2^-38 flushes to 0: a relative change of a row sum (>= ~1) of <= N 2^-39).
+// The exponent argument needs p 2^14 <= 65504, i.e. rows of norm <= 1: ms_split_kernel measures the row norms and
+// flags clouds that violate (|x|^2 - 1) / b^2 <= 1; flagged clouds are skipped here and done by the exact fp32 kernel.
+//
+// Data movement: X is fixed over the 50 iterations, so ms_split_kernel lays it out ONCE per call as a sequence of
+// 64-key stage images (70 KiB each: h and l planes of X [key][feature] for the first product and of X^T [feature][key]
+// for the second, rows padded by 16 B -> conflict-free ds_read_b128, element order = the MFMA operand slot order so
+// that every operand is one 16-byte read).  A stage image is copied to LDS by LDS-DMA (global_load_lds_dwordx4: linear
+// copy, no staging registers), double buffered, one barrier per 64 keys.
+// One workgroup = 256 query rows (8 waves x 32) x all keys x all iterations; Q lives in registers as MFMA B operands,
+// the O^T accumulator layout is the Q operand layout of the next iteration (as in ms_iterate.hip).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Stage image for KT keys (KT = 64: 70 KiB, one 8-wave workgroup per CU; KT = 32: 37 KiB, two 4-wave workgroups per CU)
+template <int KT_>
+struct StageLayout {
+    static constexpr int KT = KT_;
+    static constexpr int XROW = 272;                     // bytes per key row of an X plane: 128 halves + 16 pad
+    static constexpr int TROW = 2 * KT + 16;             // bytes per feature row of an X^T plane: KT halves + 16 pad
+    static constexpr int XPLANE = KT * XROW;
+    static constexpr int TPLANE = 128 * TROW;
+    static constexpr int OFF_XH = 0, OFF_XL = XPLANE, OFF_TH = 2 * XPLANE, OFF_TL = 2 * XPLANE + TPLANE;
+    static constexpr int STAGE = 2 * XPLANE + 2 * TPLANE;        // 71680 / 37888 B: whole 1 KiB DMA pieces
+    static_assert(STAGE % 1024 == 0, "stage image must be a whole number of wave-sized DMA pieces");
+};
+constexpr float SCALE_X = 2048.0f;               // 2^11
+constexpr float LOG2_SCALE_P = 14.0f;            // P is produced as 2^14 p
+constexpr float UNSCALE_Q = 1.0f / 2048.0f;
+constexpr float UNSCALE_O = 1.0f / 2048.0f;      // O carries 2^11 (X) * 2^14 (P); the row sum carries 2^14
+
+// position of element m (0..31) of a 32-group in MFMA operand slot order: the accumulator row of register r on lane
+// half hi is (r & 3) + 8 (r >> 2) + 4 hi; slot (j = r >> 3, hi, i = r & 7) sits at j * 16 + hi * 8 + i
+__host__ __device__ constexpr int slot_pos(int m) {
+    return (m >> 4) * 16 + ((m >> 2) & 1) * 8 + ((m >> 3) & 1) * 4 + (m & 3);
+}
+
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// X [B, N, 128] fp32 -> stage images [B, nst, STAGE] + per-cloud fallback flag. One workgroup per (stage, cloud).
+template <int KT_>
+__global__ __launch_bounds__(256) void ms_split_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                       uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
+                                                       int nst) {
+    using L = StageLayout<KT_>;
+    constexpr int KT = L::KT, XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t img[];    // STAGE bytes
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    for (int i = tid; i < STAGE / 16; i += 256) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    float n2max = 0.f;
+    for (int e = tid; e < KT * 32; e += 256) {             // one float4 of one key row per step
+        const int kk = e >> 5, d0 = (e & 31) * 4;
+        const int key = stage * KT + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * 128 + d0);
+        float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);      // 32 lanes = one key row
+        n2max = fmaxf(n2max, n2);
+        const int sub = kk >> 5, km = kk & 31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + u, c = d >> 5, m = d & 31;
+            const float s = v[u] * SCALE_X;
+            const h16 h = (h16)s;
+            const h16 l = (h16)(s - (float)h);
+            const int xo = kk * XROW + 2 * (c * 32 + slot_pos(m));
+            const int to = d * TROW + 2 * (sub * 32 + slot_pos(km));
+            *(h16*)(img + OFF_XH + xo) = h;
+            *(h16*)(img + OFF_XL + xo) = l;
+            *(h16*)(img + OFF_TH + to) = h;
+            *(h16*)(img + OFF_TL + to) = l;
+        }
+    }
+    const float b = bw[cloud];
+    if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);           // also catches NaN rows
+    __syncthreads();
+    uint4* dst = (uint4*)(blob + ((size_t)cloud * nst + stage) * STAGE);
+    for (int i = tid; i < STAGE / 16; i += 256) dst[i] = ((const uint4*)img)[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int KT_, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16_kernel(const float* __restrict__ X,
+                                                                     const uint8_t* __restrict__ blob,
+                                                                     float* __restrict__ newX,
+                                                                     const float* __restrict__ bw,
+                                                                     const int* __restrict__ flags, int N, int iters) {
+    using L = StageLayout<KT_>;
+    constexpr int KT = L::KT, XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NSUB = KT / 32;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [2][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);          // whole clouds per XCD (common.h)
+    if (flags[cloud]) return;                            // rows not unit: the exact fp32 kernel takes this cloud
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + KT - 1) / KT;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * (32 * NW) + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    // exponent in the log2 domain with the 2^14 weight scale folded in:  log2(2^14 p) = K1 * S + K0,
+    // S = 2^22 q.x ;  -dist / b^2 / 2 = (q.x - 1) / b^2.  Rounding K1 / K0 is a relative perturbation of b by < 1e-7 /
+    // a common factor of all weights of a cloud (cancels in O / sum).
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;          // guard_exp's -75 clamp
+
+    // Q operand planes: k-step ks = 2 c + j holds features 32 c + row(8 j + i, hi), i = 0..7
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v /* 8 values, already * 2^11 */) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // LDS-DMA of one stage image: STAGE / 1024 pieces of 1 KiB, piece p -> wave p % NW
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE + lane * 16;
+        uint8_t* dst = lds + buf * STAGE;
+#pragma unroll
+        for (int t = 0; t < (STAGE / 1024 + NW - 1) / NW; ++t) {
+            const int piece = wave + NW * t;
+            if (piece < STAGE / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0,
+                                                 0);
+        }
+    };
+
+    stage_dma(0, 0);
+    __syncthreads();
+    int cur = 0;
+
+    const int xoff = li * XROW + hi * 16;               // + ks * 32            (first product A operand)
+    const int toff = li * TROW + hi * 16;               // + c * 32 * TROW + sub * 64 + j * 32   (second product)
+
+    for (int it = 0; it < iters; ++it) {
+        f32x16 o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+        float rsum = 0.f;
+        const bool fwd = (it & 1) == 0;                  // ping-pong key sweep (L2 re-use after the turn-around)
+        for (int jst = 0; jst < nst; ++jst) {
+            const int st = fwd ? jst : nst - 1 - jst;
+            const bool last = (it == iters - 1) && (jst == nst - 1);
+            if (!last) stage_dma(jst + 1 == nst ? st : (fwd ? st + 1 : st - 1), cur ^ 1);
+            const uint8_t* base = lds + cur * STAGE;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = st * KT + sub * 32;
+                if (key0 < N) {                                   // block-uniform
+                    const uint8_t* xa = base + sub * 32 * XROW + xoff;
+                    f32x16 s;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const h16x8 xh = *(const h16x8*)(xa + OFF_XH + ks * 32);
+                        const h16x8 xl = *(const h16x8*)(xa + OFF_XL + ks * 32);
+                        s = mfma16(xl, qh[ks], s);
+                        s = mfma16(xh, ql[ks], s);
+                        s = mfma16(xh, qh[ks], s);
+                    }
+                    // weights 2^14 exp(clamp(-(2 - 2 q.x) / b^2 / 2))  (mean_shift.py:60-63, guard.py:7-9)
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                    if (key0 + 32 > N) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                    }
+                    h16x8 ph[2], pl[2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        rsum += p[r];
+                        const h16 h = (h16)p[r];
+                        ph[r >> 3][r & 7] = h;
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    }
+                    const uint8_t* ta = base + toff + sub * 64;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const h16x8 th = *(const h16x8*)(ta + OFF_TH + c * 32 * TROW + j * 32);
+                            const h16x8 tl = *(const h16x8*)(ta + OFF_TL + c * 32 * TROW + j * 32);
+                            o[c] = mfma16(tl, ph[j], o[c]);
+                            o[c] = mfma16(th, pl[j], o[c]);
+                            o[c] = mfma16(th, ph[j], o[c]);
+                        }
+                }
+            }
+            __syncthreads();             // next stage landed (vmcnt drained before the barrier), this one is free
+            cur ^= 1;
+        }
+
+        // ---- row update (mean_shift.py:70-77): q <- normalize(q + (O / sum - q))
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Pipelined schedule (the default): 32-key stage images, THREE LDS buffers, one 8-wave workgroup per CU.
+//   * the A operands of both products travel through a 4-slot register ring, loaded three MFMA steps (9 MFMAs) ahead
+//     of their use -- across the phase boundary and across blocks -- so no ds_read latency sits in front of an MFMA
+//     (the first version waited for every operand pair right after issuing it: ~1 LDS latency per 3 MFMAs);
+//   * waves 0-3 and 4-7 (a SIMD hosts wave w and w + 4) run half a block out of phase: per block the first group does
+//     [S, weights | barrier | O-product], the second [barrier | S, weights, O-product], so that one wave's exponentials
+//     and fp16 splits overlap the other's MFMAs instead of both stalling the matrix pipe at the same time;
+//   * block n lives in buffer n % 3. The barrier of block n (B_n) is passed once every wave has drained the DMA of
+//     block n + 1 (issued after B_{n-1}) and finished every read of block n - 1 (both groups are past its O-product), so
+//     after B_n the DMA of block n + 2 may overwrite buffer (n - 1) % 3 and block n + 1 may be read -- which is what the
+//     ring prefetch at the end of block n's O-product does.
+// CHUNKED (few clouds per call: 40 workgroups per 10 000-point cloud cannot fill 256 CUs): one workgroup = 256 queries x
+// ONE CHUNK of the stages x ONE iteration. Q is the current iterate `Qin` (fp32), the un-normalised partial (sum p x,
+// sum p) goes to a workspace and ms_combine_kernel (ms_iterate.hip) finishes the iteration, one launch pair per
+// iteration -- the schedule of ms_partial_d128_kernel with the split-fp16 inner loop.
+template <bool STAGGER, bool CHUNKED = false>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16p_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    const bool late = STAGGER && wave >= 4;              // second group: barrier first
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
+    const int nst = (N + 31) >> 5;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 4 w .. 4 w + 3 through the instruction's immediate
+    // offset (it applies to the global and to the LDS address alike), waves 0-4 also piece 32 + w; scalar bases + one
+    // per-lane 32-bit offset, no per-piece address registers
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once (advance() never
+    int st_cur = s0, st_dma = s0;                        // reaches a turning point inside the chunk's blocks)
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(s0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 2
+    __syncthreads();
+
+    // operand ring: step t of a block uses slot t & 3; steps 0-7 = first product (k-step t), 8-15 = second product
+    // (feature tile (t - 8) >> 1, key half (t - 8) & 1); step t's loads are issued after step t - 3's MFMAs
+    h16x8 fa[4], fb[4];
+    const int xoff = li * XROW + hi * 16;
+    const int toff = li * TROW + hi * 16;
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+    if (total > 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ring_load(t, lds);
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % 3
+    h16x8 ph[2], pl[2];
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const int key0 = st_cur * 32;
+
+        auto first_product_and_weights = [&]() {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                s = mfma16(fb[t & 3], qh[t], s);
+                s = mfma16(fa[t & 3], ql[t], s);
+                s = mfma16(fa[t & 3], qh[t], s);
+                ring_load(t + 3, base);
+                __builtin_amdgcn_sched_barrier(0);       // keep the loads three steps ahead of their use
+            }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+            if (key0 + 32 > N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                rsum += p[r];
+                const h16 h = (h16)p[r];
+                ph[r >> 3][r & 7] = h;
+                pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+            }
+        };
+
+        if (!late) first_product_and_weights();
+        // this wave's pieces of block n + 1 (issued after B_{n-1}, a whole block ago) must have landed before it passes B_n:
+        // stated explicitly instead of relying on where the compiler drains vmcnt
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // B_n
+        if (n + 2 < total) stage_dma(st_dma, buf == 0 ? 2 : buf - 1);       // block n + 2 -> buffer (n + 2) % 3
+        advance(st_dma, fwd_dma);
+        if (late) first_product_and_weights();
+
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            o[c] = mfma16(fb[t & 3], ph[j], o[c]);
+            o[c] = mfma16(fa[t & 3], pl[j], o[c]);
+            o[c] = mfma16(fa[t & 3], ph[j], o[c]);
+            if (t + 3 < 16) ring_load(t + 3, base);
+            else if (n + 1 < total) ring_load(t + 3 - 16, nbase);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (sweep_end) {
+            const float rs = rsum + xor32(rsum);
+            const float Dinv = UNSCALE_O / rs;
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float q =
+                        ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                    const float m = o[c][r] * Dinv - q;
+                    const float nq = q + m;
+                    o[c][r] = nq;
+                    n2 += nq * nq;
+                }
+            n2 += xor32(n2);
+            const float nrm = sqrtf(n2);
+            if (n == total - 1) {
+                if (qrow < N) {
+                    float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                       o[c][4 * g + 3] / nrm};
+                            *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                        split_q(2 * c + j, v);
+                    }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+                rsum = 0.f;
+            }
+        }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Software-pipelined schedule (default since the end of round 2): the exponentials and fp16 splits of block n are issued
+// BETWEEN the MFMAs of block n + 1's first product, inside the same wave; then block n's second product. Same stage images,
+// same three LDS buffers, same operand ring and the same MFMA order per accumulator as ms_iterate_d128_f16p_kernel (hence
+// the same bits); one barrier per block, placed after step 13 of the second product (the last step that still loads from
+// the block's buffer), after which block n + 3 is copied into that buffer.
+// (ring distance 3 was tried with the 5-MFMA form, whose second product issues one operand read per MFMA: the four extra
+// live operand registers spill inside the loop -- 836 instead of 337 ms)
+#ifndef F16Q_RING_DISTANCE
+#define F16Q_RING_DISTANCE 2
+#endif
+// PL = false ("f16h", 5 MFMAs per block pair instead of 6): the weights enter the second product -- and the row sum, consistently --
+// as their fp16 heads only, O = sum_j fp16(2^14 p_j) (xh_j + xl_j) / sum_j fp16(2^14 p_j): an exactly evaluated weighted mean
+// under weights perturbed by <= 2^-12 relative, independently per key. The perturbation of a row is
+// sum_j p_j e_j (x_j - o) / sum_j p_j ~ 2^-12 / sqrt(3) * (spread of the keys under the kernel) / sqrt(#effective keys):
+// 1e-7 .. 9e-7 on the golden snapshots (tools/f16split_emulation.py) against their 2e-6 / 5e-6 / 1e-5 tolerances. The first
+// product keeps its three terms: an error there is amplified by 1 / b^2.
+template <bool CHUNKED = false, bool PL = true, int RD_ = F16Q_RING_DISTANCE>
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16q_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr,
+                                                                      int* __restrict__ lowq = nullptr) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int RD = RD_;                               // the operand ring runs RD steps ahead
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
+    const int nst = (N + 31) >> 5;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 4 w .. 4 w + 3 through the instruction's immediate
+    // offset (it applies to the global and to the LDS address alike), waves 0-4 also piece 32 + w; scalar bases + one
+    // per-lane 32-bit offset, no per-piece address registers
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once
+    int st_cur = s0, st_dma = s0;
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(s0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);
+    if (total > 2) stage_dma(st_dma, 2);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    h16x8 fa[4], fb[4];
+    // Per-lane LDS offsets of the operand reads. They are loop invariants, and the register allocator keeps invariants that
+    // live across the (register-hungry) row update in scratch, reloading them in the hot loop -- where a reload's vmcnt wait
+    // also waits for the stage DMA issued moments earlier. So they are recomputed per block from a lane id the compiler
+    // cannot hoist (5 VALU instructions per block).
+    int xoff = li * XROW + hi * 16;
+    int toff = li * TROW + hi * 16;
+    auto refresh_offsets = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        xoff = (l & 31) * XROW + (l >> 5) * 16;
+        toff = (l & 31) * TROW + (l >> 5) * 16;
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+    // first product of a block outside the pipeline (first block of the launch and of every sweep: Q has just changed),
+    // operands read directly; same MFMA order as the pipelined form -> same bits
+    auto plain_first_product = [&](const uint8_t* base) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+            s = mfma16(l, qh[t], s);
+            s = mfma16(a, ql[t], s);
+            s = mfma16(a, qh[t], s);
+        }
+        return s;
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % 3
+    i32x4 phv[2], plv[2];                                 // weights of the current block: two accumulator rows (fp16 pair) per dword
+    f32x16 s_cur;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+    if (total > 0) s_cur = plain_first_product(lds);
+    if (total > 1) {
+#pragma unroll
+        for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
+    }
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const uint8_t* n2base = lds + (nbuf == 2 ? 0 : nbuf + 1) * STAGE;
+        const int key0 = st_cur * 32;
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
+        const bool has_next = n + 1 < total && !sweep_end;
+        const bool tail = key0 + 32 > N;
+        refresh_offsets();
+
+        // weights of block n from s_cur, two accumulator rows at a time; TAIL: the cloud's last, partly filled stage
+        auto weights2 = [&](int t, auto tail_c) {
+            float p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * t + u;
+                p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
+                if (decltype(tail_c)::value && key0 + mfma_row(r, hi) >= N) p[u] = 0.f;
+                if (PL) rsum += p[u];
+            }
+            const h16x2 h = {(h16)p[0], (h16)p[1]};
+            phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            if (PL) {
+                const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+                plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            } else {
+                rsum += (float)h[0] + (float)h[1];          // the row sum of the weights the product actually uses
+            }
+        };
+
+        // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
+        // (Measured on gfx950, tools/micro/mfma_valu_overlap.hip: VALU work of ANOTHER wave of the SIMD does not run under
+        // a wave's MFMAs -- 94 % of the serial time -- while independent VALU instructions interleaved into the SAME wave's
+        // MFMA stream do; the earlier schedules, staggered or not, ran matrix and vector phases back to back.)
+        f32x16 s_next;
+        auto phase1 = [&](auto tail_c) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_next = mfma16(fb[0], qh[0], z);
+                } else {
+                    s_next = mfma16(fb[t & 3], qh[t], s_next);
+                }
+                weights2(t, tail_c);
+                s_next = mfma16(fa[t & 3], ql[t], s_next);
+                s_next = mfma16(fa[t & 3], qh[t], s_next);
+                if (t + RD < 8) ring_load(t + RD, nbase);
+                else ring_load(t + RD, base);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_next) {
+            if (tail) phase1(std::true_type{});
+            else phase1(std::false_type{});
+        } else {                                          // last block of a sweep / of the launch: nothing to overlap with
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (tail) weights2(t, std::true_type{});
+                else weights2(t, std::false_type{});
+                if (t + RD >= 8) ring_load(t + RD, base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- phase 2: second product of block n. After step 13 nobody reads buffer n any more and everybody's pieces of
+        // block n + 2 (issued a block ago) have landed: barrier, then block n + 3 -> buffer n, and the ring moves on to
+        // block n + 2's first-product operands.
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
+            o[c] = mfma16(fb[t & 3], phj, o[c]);
+            if (PL) {
+                const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+                o[c] = mfma16(fa[t & 3], plj, o[c]);
+            }
+            o[c] = mfma16(fa[t & 3], phj, o[c]);
+            if (t + RD < 16) ring_load(t + RD, base);
+            else if (n + 2 < total) ring_load(t + RD - 16, n2base);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 15 - RD) {                            // the last step that loads from this block's buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (n + 3 < total) stage_dma(st_dma, buf);
+                advance(st_dma, fwd_dma);
+            }
+        }
+
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (!sweep_end) {
+            s_cur = s_next;
+            continue;
+        }
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        // The weighted mean of a row nearly cancels (|o| < 1/2: unstructured rows under a bandwidth that spans the cloud): the
+        // normalisation would amplify the rounding of the fp16-head weights by 1 / |o|. Flag the cloud; the launcher re-runs
+        // flagged clouds with (h, l) weights behind this launch.
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
+        if (n == total - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm, o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+            s_cur = plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
+        }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The software-pipelined kernel on ROW-MAJOR-ONLY stage images (end of round 2): the second product's A operand -- 8 keys of
+// one feature per lane -- comes from the same [key][feature] planes the first product reads, through gfx950's transpose read
+// (ds_read_b64_tr_b16), so the image drops its two transposed planes: 17 KiB per 32-key stage instead of 37 (17 LDS-DMA pieces
+// per block instead of 37, half the L2 / Infinity Cache traffic and half the LDS writes). Features are in natural order;
+// the O^T accumulator -> Q operand hand-off costs one half-wave exchange per row and iteration instead of being free.
+struct StageLayoutN {
+    static constexpr int XROW = 272, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, STAGE = 2 * XPLANE;   // 17408 B
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");
+};
+// accumulator row m = 16 a + 4 b + c  <->  image row sigma(m) = 16 a + 4 c + b (a 4 x 4 transpose inside every group of 16 rows)
+__host__ __device__ constexpr int sigma_row(int m) { return 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3); }
+
+// Stage image of the "E" kernel: the row-major planes + an fp8 (e4m3) image of the l plane TRANSPOSED, [128 features][32 keys],
+// 48-byte rows (conflict-free ds_read_b128: 12 dwords apart), for the fp8 correction term of the second product: byte p of
+// feature row f = fp8(2^6 l) of the key in image row sigma(m), m = mfma_row(p & 15, p >> 4) -- the k order in which a lane
+// pair's 16 + 16 weights of a stage form the B operand of v_mfma_f32_32x32x64_f8f6f4.
+struct StageLayoutE {
+    static constexpr int XROW = 272, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, OFF_T8 = 2 * XPLANE, T8ROW = 48,
+                         STAGE = 2 * XPLANE + 128 * T8ROW;                                                    // 23552 B
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");
+};
+
+// X [B, N, 128] fp32 -> row-major stage images [B, nst, 17408] (h plane | l plane, rows = keys in natural order, 272 B apart)
+template <bool E = false>                          // E: StageLayoutE images (row-major planes + fp8 transposed l plane)
+__global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                         uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
+                                                         int nst) {
+    using L = std::conditional_t<E, StageLayoutE, StageLayoutN>;
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
+    float n2max = 0.f;
+    for (int e = tid; e < 32 * 32; e += 256) {              // one float4 of one key row per step
+        const int kk = e >> 5, d0 = (e & 31) * 4;
+        const int key = stage * 32 + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * 128 + d0);
+        float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+        n2max = fmaxf(n2max, n2);
+        typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = v[u] * SCALE_X;
+            const h16 h = (h16)sc;
+            hh[u] = h;
+            ll[u] = (h16)(sc - (float)h);
+        }
+        *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
+        *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+        if constexpr (E) {
+            const int m = sigma_row(kk);                                   // accumulator row of image row kk (sigma is an involution)
+            const int pb = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);   // m = mfma_row(r, hi): hi = (m >> 2) & 1, r = (m & 3) + 4 (m >> 3)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dst[StageLayoutE::OFF_T8 + (d0 + u) * StageLayoutE::T8ROW + pb] =
+                    (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32((float)ll[u] * 64.0f, 0.f, 0, false) & 0xFF);
+        }
+    }
+    if (E) {                                                  // pad bytes of the fp8 rows
+        for (int i = tid; i < 128 * 4; i += 256)
+            *(uint32_t*)(dst + StageLayoutE::OFF_T8 + (i >> 2) * StageLayoutE::T8ROW + 32 + 4 * (i & 3)) = 0u;
+    }
+    if (tid < 64) {                                          // the 16 pad bytes of every row (never read as data)
+        const int kk = tid & 31, pl = tid >> 5;
+        *(uint4*)(dst + pl * L::XPLANE + kk * L::XROW + 256) = make_uint4(0, 0, 0, 0);
+    }
+    const float b = bw[cloud];
+    if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
+}
+
+// E (one-launch form, fp16-head weights only; "4.5 MFMAs"): the x_l term of the second product, a 2^-12 correction that only
+// needs ~5 % relative accuracy because it averages over the keys, runs on the fp8 matrix pipe at twice the rate --
+// v_mfma_f32_32x32x64_f8f6f4 takes 64 keys, so the blocks of a sweep are paired: the first block of a pair keeps its weights as
+// fp8 (2^8 p, 4 registers); a lane half's 32 k-slots are its own 16 keys of the first stage + its own 16 keys of the second, so
+// the second block's fp8 weights complete the B operand in place and four fp8 MFMAs add sum p8 l8 over both stages to O
+// (2^8 p x 2^6 2^11 x_l = the accumulator's 2^25 scale). The A operand comes from the fp8 transposed l planes of StageLayoutE
+// (16 bytes from the previous block's buffer, 16 from the current one): four stage buffers. The fp16 part of the second product is one MFMA per step (p~ x_h). tools/micro/fp8_mfma_probe.hip: operand layout,
+// 64 cycles per instruction beside fp16 MFMAs.
+template <bool CHUNKED = false, bool PL = true, bool E = false>      // PL: see ms_iterate_d128_f16q_kernel
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const float* __restrict__ X,
+                                                                      const uint8_t* __restrict__ blob,
+                                                                      float* __restrict__ newX,
+                                                                      const float* __restrict__ bw,
+                                                                      const int* __restrict__ flags, int N, int iters,
+                                                                      const float* __restrict__ Qin = nullptr,
+                                                                      float* __restrict__ partO = nullptr,
+                                                                      float* __restrict__ partS = nullptr,
+                                                                      int* __restrict__ lowq = nullptr,
+                                                                      int blob_stride = 0 /* bytes between stage images; 0 = STAGE */) {
+    static_assert(!E || (!CHUNKED && !PL), "the fp8 correction exists for the one-launch heads-only form");
+    using L = std::conditional_t<E, StageLayoutE, StageLayoutN>;
+    constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int NBUF = E ? 4 : 3;
+    constexpr int RD = F16Q_RING_DISTANCE;                              // the operand ring runs RD steps ahead
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // wave id in an SGPR
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;       // where the query rows come from
+    const int nst = (N + 31) >> 5;
+    const size_t bstride = blob_stride ? (size_t)blob_stride : (size_t)STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * bstride;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int nchunk = CHUNKED ? gridDim.z : 1, chunk = CHUNKED ? blockIdx.z : 0;
+    const int s0 = (int)((long)chunk * nst / nchunk), s1 = (int)((long)(chunk + 1) * nst / nchunk);
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+    // Q operand of k-step ks: features 16 ks + 8 hi + i in natural order (the stage images are row-major, unpermuted)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 16 * ks + 8 * hi + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+        }
+        split_q(ks, v);
+    }
+
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 2 w, 2 w + 1 (immediate offset), wave 0 also piece 16
+    static_assert(NPIECE == (E ? 23 : 17), "piece distribution below is written for 17 / 23 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * bstride;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 2048 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 2048);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        if (E ? wave < 7 : wave == 0)                  // pieces 16 .. 22 (E) / piece 16
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (16 + (E ? wave : 0)) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (16 + (E ? wave : 0)) * 1024), 16, 0, 0);
+    };
+    // ping-pong stage sequence 0 .. nst-1, nst-1 .. 0, 0 .. : one step
+    auto advance = [&](int& st, bool& fwd) {
+        if (fwd) {
+            if (st == nst - 1) fwd = false; else ++st;
+        } else {
+            if (st == 0) fwd = true; else --st;
+        }
+    };
+
+    const int total = CHUNKED ? s1 - s0 : iters * nst;   // CHUNKED: stages s0 .. s1 - 1 in order, once
+    int st_cur = s0, st_dma = s0;
+    bool fwd_cur = true, fwd_dma = true;
+    if (total > 0) stage_dma(s0, 0);
+    advance(st_dma, fwd_dma);
+    if (total > 1) stage_dma(st_dma, 1);
+    advance(st_dma, fwd_dma);
+    if (total > 2) stage_dma(st_dma, 2);
+    advance(st_dma, fwd_dma);                            // st_dma = stage of block 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    h16x8 fa[4], fb[4];
+    // Per-lane LDS offsets of the operand reads (recomputed per block from a lane id the compiler cannot hoist: invariants
+    // that live across the register-hungry row update end up in scratch, and a reload's vmcnt wait in the hot loop also waits
+    // for the stage copy in flight).
+    //   first product: accumulator row m reads image row sigma(m), sigma(16 a + 4 b + c) = 16 a + 4 c + b -- a permutation
+    //     inside each group of 16 rows, conflict-free for ds_read_b128 (its four 16-lane groups see 16 distinct rows mod 16,
+    //     272-byte rows = 4 banks apart), chosen so that
+    //   second product: the four keys of one transpose read (accumulator rows rho .. rho + 3) sit in image rows FOUR apart
+    //     (16 banks): ds_read_b64_tr_b16 -- every lane passes the address of 4 consecutive features of one key, a 16-lane
+    //     group gets back the 4 keys x 16 features block transposed: lane = feature, 4 keys. Its conflict groups are the two
+    //     32-lane halves: lanes 0-15 (features 0-15 of the tile) and 16-31 (features 16-31, 8 banks further) read the same
+    //     four rows, so rows 16 banks apart make the 64 dwords of a half distinct. (The first version put the rows two
+    //     apart, 8 banks: lanes 16-31 then collided with the next row of lanes 0-15 -- SQ_LDS_BANK_CONFLICT 1.3 extra cycles
+    //     per LDS instruction, a third of the LDS-array cycles.) No transposed planes in the image: 17 KiB per stage instead of 37.
+    int xoff, toff;
+    auto refresh_offsets = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const int m = l & 31, h = l >> 5;
+        const int sig = 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3);
+        xoff = sig * XROW + h * 16;
+        const int i16 = l & 15;
+        toff = (4 * (i16 >> 2) + h) * XROW + 32 * ((l >> 4) & 1) + 8 * (i16 & 3);
+    };
+    refresh_offsets();
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {       // keys 16 j + {4 hi .. + 3, 8 + 4 hi .. + 3} of feature 32 c + li
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {      // t in 0..15, compile-time after unrolling
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            if (!E) fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+    // first product of a block outside the pipeline (first block of the launch and of every sweep: Q has just changed),
+    // operands read directly; same MFMA order as the pipelined form -> same bits
+    auto plain_first_product = [&](const uint8_t* base) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+            s = mfma16(l, qh[t], s);
+            s = mfma16(a, ql[t], s);
+            s = mfma16(a, qh[t], s);
+        }
+        return s;
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    int buf = 0;                                          // buffer of the current block = n % NBUF
+    // E: fp8 weights (2^8 p, byte r = accumulator row r) of this block and of the pair's first block; position in the sweep
+    // the B operand of the pair's fp8 MFMAs, assembled in place: dwords 0-3 = the first block's weights, 4-7 = the second's
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    v8i p8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned p8cur[E ? 4 : 1] = {};
+    int in_sweep = 0;
+    i32x4 phv[2], plv[2];                                 // weights of the current block: two accumulator rows (fp16 pair) per dword
+    f32x16 s_cur;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+    if (total > 0) s_cur = plain_first_product(lds);
+    if (total > 1) {
+#pragma unroll
+        for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
+    }
+
+    for (int n = 0; n < total; ++n) {
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const uint8_t* n2base = lds + (nbuf == NBUF - 1 ? 0 : nbuf + 1) * STAGE;
+        const int pbuf = buf == 0 ? NBUF - 1 : buf - 1;      // E: the previous block's buffer (its fp8 plane is still there)
+        const int key0 = st_cur * 32;
+        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
+        const bool has_next = n + 1 < total && !sweep_end;
+        const bool tail = key0 + 32 > N;
+        refresh_offsets();
+
+        // weights of block n from s_cur, two accumulator rows at a time; TAIL: the cloud's last, partly filled stage
+        auto weights2 = [&](int t, auto tail_c) {
+            float p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * t + u;
+                p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[r], K1, K0), TMIN));
+                if (decltype(tail_c)::value && key0 + sigma_row(mfma_row(r, hi)) >= N) p[u] = 0.f;
+                if (PL) rsum += p[u];
+            }
+            const h16x2 h = {(h16)p[0], (h16)p[1]};
+            phv[t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            if constexpr (E) {                                // bytes 2 t, 2 t + 1 of the lane's 16 fp8 weights
+                // (v_cvt_scalef32_pk_fp8_f32, which divides by a scale operand and would save the two multiplies, is slower here:
+                // 365 instead of 288 ms)
+                const float a8 = p[0] * 0.015625f, c8 = p[1] * 0.015625f;
+                if (t & 1) p8cur[t >> 1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a8, c8, (int)p8cur[t >> 1], true);
+                else p8cur[t >> 1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a8, c8, (int)p8cur[t >> 1], false);
+            }
+            if (PL) {
+                const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+                plv[t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            } else {
+                // (one v_dot2c_f32_f16 against (1, 1) per pair instead of two conversions + two adds was tried in the f16r kernel: 361 vs
+                // 287 ms -- the dot instruction is slow beside the MFMAs and the allocator moved a reload into the loop)
+                rsum += (float)h[0] + (float)h[1];
+            }
+        };
+
+        // ---- phase 1: first product of block n + 1 with the exponentials and splits of block n BETWEEN its MFMAs.
+        // (Measured on gfx950, tools/micro/mfma_valu_overlap.hip: VALU work of ANOTHER wave of the SIMD does not run under
+        // a wave's MFMAs -- 94 % of the serial time -- while independent VALU instructions interleaved into the SAME wave's
+        // MFMA stream do; the earlier schedules, staggered or not, ran matrix and vector phases back to back.)
+        f32x16 s_next;
+        auto phase1 = [&](auto tail_c) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_next = mfma16(fb[0], qh[0], z);
+                } else {
+                    s_next = mfma16(fb[t & 3], qh[t], s_next);
+                }
+                weights2(t, tail_c);
+                s_next = mfma16(fa[t & 3], ql[t], s_next);
+                s_next = mfma16(fa[t & 3], qh[t], s_next);
+                if (t + RD < 8) ring_load(t + RD, nbase);
+                else ring_load(t + RD, base);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_next) {
+            if (tail) phase1(std::true_type{});
+            else phase1(std::false_type{});
+        } else {                                          // last block of a sweep / of the launch: nothing to overlap with
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (tail) weights2(t, std::true_type{});
+                else weights2(t, std::false_type{});
+                if (t + RD >= 8) ring_load(t + RD, base);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- phase 2: second product of block n. After step 13 nobody reads buffer n any more and everybody's pieces of
+        // block n + 2 (issued a block ago) have landed: barrier, then block n + 3 -> buffer n, and the ring moves on to
+        // block n + 2's first-product operands.
+        // E: this block closes a pair (odd position in the sweep), or it is the unpaired last block of a sweep. A lane's 32 k-slots
+        // of the fp8 MFMA are its OWN 16 keys of the first stage followed by its own 16 keys of the second (k = 32 hi + ...):
+        // the B operand is just the two blocks' fp8 weights side by side -- no exchange between the lane halves.
+        const bool pair_second = E && (in_sweep & 1) != 0;
+        const bool pair_flush = E && !pair_second && sweep_end;
+        if constexpr (E) {
+            if (pair_second) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p8[4 + i] = (int)p8cur[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { p8[i] = (int)p8cur[i]; p8[4 + i] = 0; }     // (flush: no second stage -> zero weights)
+            }
+        }
+        // fp8 transposed l plane, 16 bytes = this lane half's 16 keys of a stage: first stage from the previous block's buffer
+        // (flush: this block's), second stage from this block's
+        const uint8_t* t8a = lds + (pair_second ? pbuf : buf) * STAGE + (E ? StageLayoutE::OFF_T8 : 0) + li * 48 + 16 * hi;
+        const uint8_t* t8b = lds + buf * STAGE + (E ? StageLayoutE::OFF_T8 : 0) + li * 48 + 16 * hi;
+        // The fp8 A operand of feature tile cc is read one step before its MFMA (steps 9 .. 12, before the barrier of step 13).
+        const bool do8 = E && (pair_second || pair_flush);
+        v8i a8;
+        auto load_a8 = [&](int cc) {                          // two 16-byte reads straight into the halves of the 8-register operand
+            const i32x4 lo = *(const i32x4*)(t8a + cc * 32 * 48), hi4 = *(const i32x4*)(t8b + cc * 32 * 48);
+            a8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        if (do8) load_a8(0);
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const h16x8 phj = __builtin_bit_cast(h16x8, phv[j]);
+            if (!E) o[c] = mfma16(fb[t & 3], phj, o[c]);
+            if (PL) {
+                const h16x8 plj = __builtin_bit_cast(h16x8, plv[j]);
+                o[c] = mfma16(fa[t & 3], plj, o[c]);
+            }
+            o[c] = mfma16(fa[t & 3], phj, o[c]);
+            if constexpr (E) {
+                if (do8 && t >= 9 && t < 13) {                    // feature tile t - 9, 64 keys
+                    const int cc = t - 9;
+                    o[cc] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, p8, o[cc], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    if (cc < 3) load_a8(cc + 1);
+                }
+            }
+            if (t + RD < 16) ring_load(t + RD, base);
+            else if (n + 2 < total) ring_load(t + RD - 16, n2base);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 15 - RD) {                            // the last step that loads from this block's buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // three buffers: block n + 3 replaces block n; E: it replaces block n - 1, whose fp8 plane was read above
+                if (n + 3 < total) stage_dma(st_dma, E ? pbuf : buf);
+                advance(st_dma, fwd_dma);
+            }
+        }
+        if constexpr (E) in_sweep = sweep_end ? 0 : in_sweep + 1;
+
+        advance(st_cur, fwd_cur);
+        buf = nbuf;
+        if (!sweep_end) {
+            s_cur = s_next;
+            continue;
+        }
+        // ---- end of a sweep: row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        // current Q in the accumulator layout (inverse of the hand-off below)
+        float qacc[4][16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;           // g = 0
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;   // g = 1
+                    const float keep = hi ? e1 : e0, send = hi ? e0 : e1;
+                    const float recv = __shfl_xor(send, 32, 64);
+                    // own half g = hi holds register 4 (2 j + hi) + u; the partner's element is register 4 (2 j + 1 - hi) + u
+                    qacc[c][8 * j + u] = hi ? recv : keep;
+                    qacc[c][8 * j + 4 + u] = hi ? keep : recv;
+                }
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = qacc[c][r];
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
+        if (n == total - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm, o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+            // accumulator (feature 32 c + (r & 3) + 8 (r >> 2) + 4 hi) -> Q operand (feature 16 ks + 8 hi + i): element
+            // i = 4 g + u of k-step 2 c + j is register 4 (2 j + hi) + u of lane half g -- own half for g = hi, the partner
+            // lane's otherwise (one exchange per row and iteration)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = (o[c][8 * j + u] / nrm) * SCALE_X, bq = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                        const float keep = hi ? bq : a, send = hi ? a : bq;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        v[u] = hi ? recv : keep;
+                        v[4 + u] = hi ? keep : recv;
+                    }
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+            s_cur = plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
+        }
+    }
+    if (CHUNKED) {
+        // partial of this chunk, unscaled: O carries 2^11 (X) * 2^14 (P), the row sum 2^14
+        const float rs = rsum + xor32(rsum);
+        if (qrow < N) {
+            const size_t slot = ((size_t)cloud * N + qrow) * nchunk + chunk;
+            float* out = partO + slot * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    constexpr float U = 1.0f / 33554432.0f;          // 2^-25
+                    f32x4 v = {o[c][4 * g] * U, o[c][4 * g + 1] * U, o[c][4 * g + 2] * U, o[c][4 * g + 3] * U};
+                    *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) partS[slot] = rs * (1.0f / 16384.0f);
+        }
+        return;
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Block-sparse schedule on the pipelined split-fp16 kernel (round 2; the fp32 version is ms_sparse.hip).
+// Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure, together with two unit reference
+// vectors per tile (normalised means of two groups of its rows) and cos(alpha) of each, alpha = the widest angle between
+// the reference and a row of its group. Every iteration
+//   (1) every wave measures its 32 current queries against ALL tile references: S = M Q^T on the matrix pipe (fp16 head
+//       parts only: |error| <= 5e-4 in the dot product, covered by the threshold's slack), 8 MFMAs per 32 references;
+//   (2) it marks the stages it needs: by the triangle inequality on the unit sphere angle(q, x) >= angle(q, m) - alpha for
+//       every key x within alpha of a reference m, so a tile all of whose rows lie in caps with
+//       q . m <= cos(theta + alpha + margin) - slack  for all 32 queries carries only weights <= e^skip for them (theta = the
+//       angle at which the kernel weight drops to e^skip). A tile has TWO references, each covering a part of its rows: the
+//       tile at the border between two clusters of the sorted order would otherwise be wide open and needed by everybody;
+//   (3) the workgroup compacts the union of its 8 waves' marks into a stage list (thread s owns stage s: nst <= 512);
+//   (4) the pipeline of ms_iterate_d128_f16p_kernel runs over that list only -- stages nobody needs are never copied to
+//       LDS; a wave that does not need a listed stage only takes part in its barrier; a wave whose weights of a stage all
+//       round to zero in fp16 (p 2^14 <= 2^-25: exactly the blocks whose O-contribution is 0 in the dense kernel too)
+//       skips the second product.
+// The references are staged like keys: ms_split_kernel lays M out as stage images (32 references per image), and (1)
+// copies the head planes of up to 12 images at a time into the (then idle) stage buffers.
+// The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
+// direction so that an iteration starts on the stages the previous one left in L2.
+// What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
+#ifndef F16S_NBUF
+#define F16S_NBUF 3                                    // stage buffers of the sparse kernel (4 fit -- 4 x 37 KiB + 7 KiB of tables <= 160 KiB -- and change nothing: 51.1 vs 50.5 ms)
+#endif
+constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
+
+constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
+constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
+constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
+
+template <bool STAGGER, bool PL = true>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq = nullptr) {
+    using L = StageLayout<32>;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    constexpr int MAXW = F16S_MAXW;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [F16S_NBUF][STAGE]
+    __shared__ unsigned long long wmask[8][MAXW];
+    __shared__ int slist[512];
+    __shared__ int wcount[8];
+    __shared__ float wmoved[8];
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const bool late = STAGGER && wave >= 4;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + 31) >> 5;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + rho], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+            }
+            split_q(2 * c + j, v);
+        }
+
+    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if (wave < 5)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (32 + wave) * 1024 + lane16),
+                (__attribute__((address_space(3))) void*)(dst + (32 + wave) * 1024), 16, 0, 0);
+    };
+
+    h16x8 fa[4], fb[4];
+    const int xoff = li * XROW + hi * 16;
+    const int toff = li * TROW + hi * 16;
+    auto ring_load = [&](int t, const uint8_t* base) {
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    h16x8 ph[2], pl[2];
+    unsigned long long n_listed = 0, n_first = 0, n_second = 0, n_remake = 0;      // per-wave counts (statistics only)
+
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
+    // The rows at mask time are parked in the output rows (row-private; overwritten by the result at the end).
+    int ns = 0;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous iteration's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) mx = fmaxf(mx, wmoved[w]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+        if (qrow < N) {                                  // remember where the masks were made: the row's slot of the output
+            float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 4 * g + u;
+                        v[u] = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                    }
+                    *(f32x4*)(keep + 32 * c + 8 * g + 4 * hi) = v;
+                }
+        }
+        // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
+        for (int g0 = 0; g0 < nrs; g0 += F16S_REFGROUP) {
+            const int ng = min(F16S_REFGROUP, nrs - g0);
+            if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
+            for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
+                const int im = pc / 9, piece = pc - 9 * im;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                    (__attribute__((address_space(3))) void*)(lds + im * F16S_REFBYTES + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int im = 0; im < ng; ++im) {
+                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff;
+                f32x16 sr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                unsigned word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * g + u] > th[u]);
+                        word |= ((unsigned)bal != 0u ? 1u : 0u) << (8 * g + u);              // tile row of lane half 0
+                        word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << (8 * g + u + 4);  // ... of lane half 1
+                    }
+                }
+                if (lane == 0) {                                  // a tile is needed if either of its references is near
+                    unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                    *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                }
+            }
+        }
+        if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
+        __syncthreads();
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
+        {
+            bool need = false;
+            if (tid < nst) {
+                const int w = tid >> 6, sh = tid & 63;
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) any |= wmask[v][w];
+                need = (any >> sh) & 1ull;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = 0;
+            ns = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int cnt = wcount[w];
+                if (w < wave) base += cnt;
+                ns += cnt;
+            }
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tid;
+        }
+        __syncthreads();
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        ++n_remake;
+        }   // remake
+        n_listed += ns;
+
+        // ---- (4) the pipeline over the list
+        const bool fwd = (it & 1) == 0;
+        auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
+        if (ns > 0) stage_dma(entry(0), 0);
+        if (ns > 1) stage_dma(entry(1), 1);
+        if (F16S_NBUF > 3 && ns > 2) stage_dma(entry(2), 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ns > 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) ring_load(t, lds);
+        }
+        int buf = 0;
+        for (int j = 0; j < ns; ++j) {
+            const uint8_t* base = lds + buf * STAGE;
+            const int nbuf = buf == F16S_NBUF - 1 ? 0 : buf + 1;
+            const uint8_t* nbase = lds + nbuf * STAGE;
+            const int st = entry(j);
+            const int key0 = st * 32;
+            const bool need =
+                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            bool live = false;
+
+            auto first_product_and_weights = [&]() {
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s = mfma16(fb[t & 3], qh[t], s);
+                    s = mfma16(fa[t & 3], ql[t], s);
+                    s = mfma16(fa[t & 3], qh[t], s);
+                    ring_load(t + 3, base);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                }
+                float pmax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pmax = fmaxf(pmax, p[r]);
+                    const h16 h = (h16)p[r];
+                    ph[r >> 3][r & 7] = h;
+                    if (PL) {
+                        rsum += p[r];
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    } else {
+                        rsum += (float)h;
+                    }
+                }
+                // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
+                live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
+                ++n_first;
+            };
+
+            if (!late && need) first_product_and_weights();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // B_j
+            // entry j + NBUF - 1 goes into the buffer entry j - 1 has left (every wave is past it: it passed B_j)
+            if (j + F16S_NBUF - 1 < ns) stage_dma(entry(j + F16S_NBUF - 1), buf == 0 ? F16S_NBUF - 1 : buf - 1);
+            if (late && need) first_product_and_weights();
+
+            if (live) {
+                ++n_second;
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    const int c = (t - 8) >> 1, jj = (t - 8) & 1;
+                    o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
+                    if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if (t + 3 < 16) ring_load(t + 3, base);
+                    else if (j + 1 < ns) ring_load(t + 3 - 16, nbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (j + 1 < ns) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ring_load(t, nbase);
+            }
+            buf = nbuf;
+        }
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;       // see ms_iterate_d128_f16q_kernel
+        if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
+            float ch2 = 0.f;
+            if (qrow < N) {
+                const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 k = *(const f32x4*)(keep + 32 * c + 8 * g + 4 * hi);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dlt = o[c][4 * g + u] * inv - k[u];
+                            ch2 = fmaf(dlt, dlt, ch2);
+                        }
+                    }
+            }
+            ch2 += xor32(ch2);
+            float wm = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            if (lane == 0) wmoved[wave] = wm;            // read after the barrier that opens the next iteration
+        }
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+    if (stats && lane == 0) {
+        // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
+        // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
+        if (wave == 0) atomicAdd(stats + 0, n_listed);
+        atomicAdd(stats + 1, n_first);
+        atomicAdd(stats + 2, n_second);
+        atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
+        if (wave == 0) atomicAdd(stats + 4, n_remake);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The block-sparse kernel on row-major-only stage images (ms_iterate_d128_f16r_kernel's layout and transpose reads): half the
+// bytes per listed stage -- its counters show 132 GB per launch fetched from beyond L2 for 177 GB of stage copies -- and, at
+// 17 KiB per stage, six stage buffers instead of three. An experiment that answered its question: it is 8 % SLOWER than the
+// four-plane kernel (twice the LDS read instructions in the second product), so copy traffic is not what bounds the sparse
+// schedule. Kept selectable (sed_ms_set_f16_sparse_config(0)) with its tests; not the default.
+#ifndef F16T_NBUF
+#define F16T_NBUF 6
+#endif
+#ifndef F16T_REFGROUP
+#define F16T_REFGROUP 11                              // 11 x 9 KiB reference head planes <= 6 x 17 KiB of stage buffers
+#endif
+template <bool STAGGER, bool PL = true>      // PL = false: fp16-head weights (see ms_iterate_d128_f16q_kernel)
+__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16t_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq = nullptr) {
+    using L = StageLayoutN;
+    constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
+    constexpr int MAXW = F16S_MAXW, NBUF = F16T_NBUF, REFGROUP = F16T_REFGROUP;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE] (and REFGROUP reference head planes)
+    __shared__ unsigned long long wmask[8][MAXW];
+    __shared__ int slist[512];
+    __shared__ int wcount[8];
+    __shared__ float wmoved[8];
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    int bx;
+    const int cloud = sed_xcd_cloud_block(&bx);
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    const int nst = (N + 31) >> 5;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            // slot rho = image * 32 + accumulator row m; that row reads image row sigma(m): tile 32 (image / 2) + sigma(m)
+            const int srow = sigma_row(rho & 31);
+            const int t = (rho >> 6) * 32 + srow;        // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + (rho & ~31) + srow], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
+    h16x8 qh[8], ql[8];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                      // Q operand of k-step ks: features 16 ks + 8 hi + i, natural order
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 tq = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 16 * ks + 8 * hi + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * g + u] = tq[u] * SCALE_X;
+        }
+        split_q(ks, v);
+    }
+
+    static_assert(NPIECE == 17, "piece distribution below is written for 17 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 2048 + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 2048);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * 1024 + lane16),
+                                             (__attribute__((address_space(3))) void*)(dst + 16 * 1024), 16, 0, 0);
+    };
+
+    h16x8 fa[4], fb[4];
+    // row sigma(li) of the image for the first product, transpose reads for the second: see ms_iterate_d128_f16r_kernel
+    const int xoff = sigma_row(li) * XROW + hi * 16;
+    const int toff = (4 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {
+        if (t < 8) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+
+    f32x16 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    h16x8 ph[2], pl[2];
+    unsigned long long n_listed = 0, n_first = 0, n_second = 0, n_remake = 0;      // per-wave counts (statistics only)
+
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
+    // The rows at mask time are parked in the output rows (row-private; overwritten by the result at the end).
+    int ns = 0;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous iteration's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) mx = fmaxf(mx, wmoved[w]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+        if (qrow < N) {                                  // remember where the masks were made: the row's slot of the output
+            float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = ((float)qh[ks][4 * g + u] + (float)ql[ks][4 * g + u]) * UNSCALE_Q;
+                    *(f32x4*)(keep + 16 * ks + 8 * hi + 4 * g) = v;
+                }
+        }
+        // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
+        for (int g0 = 0; g0 < nrs; g0 += REFGROUP) {
+            const int ng = min(REFGROUP, nrs - g0);
+            if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
+            for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
+                const int im = pc / 9, piece = pc - 9 * im;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                    (__attribute__((address_space(3))) void*)(lds + im * F16S_REFBYTES + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int im = 0; im < ng; ++im) {
+                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff;
+                f32x16 sr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                unsigned word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * g + u] > th[u]);
+                        word |= ((unsigned)bal != 0u ? 1u : 0u) << sigma_row(8 * g + u);              // tile of lane half 0's row
+                        word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << sigma_row(8 * g + u + 4);  // ... of lane half 1's
+                    }
+                }
+                if (lane == 0) {                                  // a tile is needed if either of its references is near
+                    unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                    *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                }
+            }
+        }
+        if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
+        __syncthreads();
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
+        {
+            bool need = false;
+            if (tid < nst) {
+                const int w = tid >> 6, sh = tid & 63;
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) any |= wmask[v][w];
+                need = (any >> sh) & 1ull;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = 0;
+            ns = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int cnt = wcount[w];
+                if (w < wave) base += cnt;
+                ns += cnt;
+            }
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tid;
+        }
+        __syncthreads();
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        ++n_remake;
+        }   // remake
+        n_listed += ns;
+
+        // ---- (4) the pipeline over the list
+        const bool fwd = (it & 1) == 0;
+        auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
+        if (ns > 0) stage_dma(entry(0), 0);
+        if (ns > 1) stage_dma(entry(1), 1);
+#pragma unroll
+        for (int pj = 2; pj < NBUF - 1; ++pj)
+            if (ns > pj) stage_dma(entry(pj), pj);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ns > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) ring_load(t, lds);
+        }
+        int buf = 0;
+        for (int j = 0; j < ns; ++j) {
+            const uint8_t* base = lds + buf * STAGE;
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+            const uint8_t* nbase = lds + nbuf * STAGE;
+            const int st = entry(j);
+            const int key0 = st * 32;
+            const bool need =
+                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            bool live = false;
+
+            auto first_product_and_weights = [&]() {
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s = mfma16(fb[t & 3], qh[t], s);
+                    s = mfma16(fa[t & 3], ql[t], s);
+                    s = mfma16(fa[t & 3], qh[t], s);
+                    ring_load(t + 2, base);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s[r], K1, K0), TMIN));
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + sigma_row(mfma_row(r, hi)) >= N) p[r] = 0.f;
+                }
+                float pmax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pmax = fmaxf(pmax, p[r]);
+                    const h16 h = (h16)p[r];
+                    ph[r >> 3][r & 7] = h;
+                    if (PL) {
+                        rsum += p[r];
+                        pl[r >> 3][r & 7] = (h16)(p[r] - (float)h);
+                    } else {
+                        rsum += (float)h;
+                    }
+                }
+                // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
+                live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
+                ++n_first;
+            };
+
+            if (need) first_product_and_weights();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // B_j
+            // entry j + NBUF - 1 goes into the buffer entry j - 1 has left (every wave is past it: it passed B_j)
+            if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
+
+            if (live) {
+                ++n_second;
+#pragma unroll
+                for (int t = 8; t < 16; ++t) {
+                    const int c = (t - 8) >> 1, jj = (t - 8) & 1;
+                    o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
+                    if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if (t + 2 < 16) ring_load(t + 2, base);
+                    else if (j + 1 < ns) ring_load(t + 2 - 16, nbase);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (j + 1 < ns) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) ring_load(t, nbase);
+            }
+            buf = nbuf;
+        }
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float qacc[4][16];                               // current Q in the accumulator layout (see ms_iterate_d128_f16r_kernel)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;
+                    const float keepv = hi ? e1 : e0, send = hi ? e0 : e1;
+                    const float recv = __shfl_xor(send, 32, 64);
+                    qacc[c][8 * j + u] = hi ? recv : keepv;
+                    qacc[c][8 * j + 4 + u] = hi ? keepv : recv;
+                }
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = qacc[c][r];
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;
+        if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
+            float ch2 = 0.f;
+            if (qrow < N) {
+                const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 k = *(const f32x4*)(keep + 32 * c + 8 * g + 4 * hi);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dlt = o[c][4 * g + u] * inv - k[u];
+                            ch2 = fmaf(dlt, dlt, ch2);
+                        }
+                    }
+            }
+            ch2 += xor32(ch2);
+            float wm = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            if (lane == 0) wmoved[wave] = wm;            // read after the barrier that opens the next iteration
+        }
+        if (it == iters - 1) {
+            if (qrow < N) {
+                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
+                                   o[c][4 * g + 3] / nrm};
+                        *(f32x4*)(out + 32 * c + 8 * g + 4 * hi) = v;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = (o[c][8 * j + u] / nrm) * SCALE_X, bq = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                        const float keepv = hi ? bq : a, send = hi ? a : bq;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        v[u] = hi ? recv : keepv;
+                        v[4 + u] = hi ? keepv : recv;
+                    }
+                    split_q(2 * c + j, v);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+        }
+    }
+    if (iters == 0 && qrow < N) {
+        float* out = newX + ((size_t)cloud * N + qrow) * 128;
+        const float* in = Xc + (size_t)qrow * 128;
+        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
+    }
+    if (stats && lane == 0) {
+        // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
+        // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
+        if (wave == 0) atomicAdd(stats + 0, n_listed);
+        atomicAdd(stats + 1, n_first);
+        atomicAdd(stats + 2, n_second);
+        atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
+        if (wave == 0) atomicAdd(stats + 4, n_remake);
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
+// cfg 0 (default): software-pipelined 8-wave kernel (exponentials of block n between the MFMAs of block n + 1) with fp16-head
+// weights in the second product (5 MFMAs per block pair) -- on row-major-only stage images (ms_iterate_d128_f16r_kernel, 17 KiB
+// per stage, transpose reads) in its one-launch and its key-chunked form; 7: the four-plane kernel
+// (ms_iterate_d128_f16q_kernel) in both forms; 6 / 5: four-plane / row-major kernel with (h, l) weights (6 MFMAs);
+// 1: round-2 pipelined kernel, wave groups in phase; 4: the same, groups half a block out of phase (the default until the
+// software-pipelined kernel); 2: first version, 64-key stages, 8 waves; 3: first version, 32-key stages, two 4-wave
+// workgroups per CU
+int g_ms_f16_cfg = 0;
+
+static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
+
+// image formats: 0 = four planes, 32-key stages (StageLayout<32>); 2 = four planes, 64-key stages; 5 = row-major only (StageLayoutN);
+// 8 = row-major + fp8 transposed l plane (StageLayoutE)
+static size_t f16_blob_bytes(int B, int N, int fmt) {
+    const size_t kt = fmt == 2 ? 64 : 32;
+    const size_t stage = fmt == 2 ? StageLayout<64>::STAGE : fmt == 5 ? StageLayoutN::STAGE : fmt == 8 ? StageLayoutE::STAGE
+                                                                                              : StageLayout<32>::STAGE;
+    return (size_t)B * ((N + kt - 1) / kt) * stage;
+}
+// format the one-launch (unchunked) kernel of a configuration reads; the key-chunked form always reads format 0
+static int f16_unchunked_fmt(int cfg) { return cfg == 2 ? 2 : cfg == 8 ? 8 : (cfg == 0 || cfg == 5) ? 5 : 0; }
+
+// stage images | "rows not unit" flags | "weighted means cancel" flags (both per cloud, 256-byte blocks)
+size_t ms_f16_workspace_bytes(int B, int N) {
+    return f16_blob_bytes(B, N, f16_unchunked_fmt(g_ms_f16_cfg)) + 2 * ((((size_t)B * sizeof(int) + 255) / 256) * 256);
+}
+static size_t f16_chunked_base_bytes(int B, int N) { return f16_blob_bytes(B, N, 0) + 2 * f16_flag_bytes(B); }
+
+template <int KT_, int NW>
+static int f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                      hipStream_t stream) {
+    using L = StageLayout<KT_>;
+    const int nst = (N + KT_ - 1) / KT_;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<KT_>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16_kernel<KT_, NW>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<KT_><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16_kernel<KT_, NW><<<dim3((N + 32 * NW - 1) / (32 * NW), B), 64 * NW, 2 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+template <bool STAGGER>
+static int f16p_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<STAGGER>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16p_kernel<STAGGER><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw,
+                                                                                                  flags, N, iters);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// PL = false: heads-only weights, clouds whose weighted means cancel are flagged in `lowq` and done again with (h, l) weights
+// by a second launch whose workgroups return at once for every other cloud
+template <bool PL>
+static int f16q_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       int* lowq, hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_split_kernel<32>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, PL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16q_kernel<false, PL><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, PL ? nullptr : lowq);
+    if (!PL)
+        ms_iterate_d128_f16q_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+template <bool PL>
+static int f16r_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       int* lowq, hipStream_t stream) {
+    using L = StageLayoutN;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, PL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16r_kernel<false, PL><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, PL ? nullptr : lowq);
+    if (!PL)
+        ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// the "4.5-MFMA" kernel: StageLayoutE images, four stage buffers; flagged clouds are redone by the (h, l) row-major kernel on the
+// same images (their row-major planes sit at the start of every stage)
+static int f16e_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       int* lowq, hipStream_t stream) {
+    using L = StageLayoutE;
+    const int nst = (N + 31) / 32;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, false, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_n_kernel<true><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_iterate_d128_f16r_kernel<false, false, true><<<dim3((N + 255) / 256, B), 512, 4 * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * StageLayoutN::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq, L::STAGE);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// key-chunked split-fp16 schedule: chunk count from N only (results do not depend on how many clouds share a launch):
+// as many chunks as fill the 256 CUs with ONE cloud's workgroups, at least 8 stages per chunk; 0 = not worth it
+int ms_f16_chunks(int N) {
+    const int nbx = (N + 255) / 256, nst = (N + 31) / 32;
+    if (N < 2560) return 0;
+    int S = 256 / nbx;
+    if (S > nst / 8) S = nst / 8;
+    return S < 2 ? 0 : S;
+}
+
+size_t ms_f16_chunked_workspace_bytes(int B, int N) {
+    return f16_chunked_base_bytes(B, N) + (size_t)B * N * ms_f16_chunks(N) * 129 * sizeof(float) + 256;
+}
+
+// one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher
+int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                          int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
+                                                          int, int*, hipStream_t),
+                          hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, 0));
+    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + f16_chunked_base_bytes(B, N)) + 255) & ~(uintptr_t)255);
+    float* partS = partO + (size_t)B * N * S * 128;
+    int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
+    if (e != hipSuccess) return (int)e;
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16p_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16q_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * StageLayoutN::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    if (g_ms_f16_cfg == 0) {          // default: key-chunked form on row-major-only stage images like the one-launch form (-2 .. 5 %
+                                      // against the four-plane kernel below, cfg 7; the blob region stays sized for four planes)
+        using LN = StageLayoutN;
+        ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        for (int it = 0; it < iters; ++it) {
+            const float* Q = it == 0 ? X : newX;
+            ms_iterate_d128_f16r_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * LN::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+            const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, lowq, stream);
+            if (rc != SED_OK) return rc;
+        }
+        if (iters > 0)
+            ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * LN::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    const bool heads = g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7 || g_ms_f16_cfg == 8;
+    for (int it = 0; it < iters; ++it) {
+        const float* Q = it == 0 ? X : newX;
+        if (g_ms_f16_cfg == 6)
+            ms_iterate_d128_f16q_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        else if (g_ms_f16_cfg == 0 || g_ms_f16_cfg == 7 || g_ms_f16_cfg == 8)
+            ms_iterate_d128_f16q_kernel<true, false><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        else
+        ms_iterate_d128_f16p_kernel<true, true><<<dim3((N + 255) / 256, B, S), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, 1, Q, partO, partS);
+        // the combine kernel sees the norm of every weighted mean: with heads-only weights it flags clouds whose means cancel
+        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, heads ? lowq : nullptr, stream);
+        if (rc != SED_OK) return rc;
+    }
+    if (heads && iters > 0)                           // flagged clouds again, (h, l) weights, all iterations in one launch
+        ms_iterate_d128_f16q_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// flags live behind the stage images; *flags_out = the per-cloud "rows not unit" flags the exact fp32 kernel reads
+int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                  int** flags_out, hipStream_t stream) {
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, f16_unchunked_fmt(g_ms_f16_cfg)));
+    int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
+    if (e != hipSuccess) return (int)e;
+    if (g_ms_f16_cfg == 2) return f16_launch<64, 8>(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 3) return f16_launch<32, 4>(B, N, iters, bw, X, newX, blob, flags, stream);
+    if (g_ms_f16_cfg == 0) return f16r_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 8) return f16e_launch(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 7) return f16q_launch<false>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 6) return f16q_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    if (g_ms_f16_cfg == 5) return f16r_launch<true>(B, N, iters, bw, X, newX, blob, flags, lowq, stream);
+    return g_ms_f16_cfg == 4 ? f16p_launch<true>(B, N, iters, bw, X, newX, blob, flags, stream)
+                             : f16p_launch<false>(B, N, iters, bw, X, newX, blob, flags, stream);
+}
+
+
+// stage images of the sorted rows | flags | stage images of the tile references | scratch flags
+size_t ms_f16_sparse_workspace_bytes(int B, int N) {
+    const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
+    return f16_blob_bytes(B, N, 0) + f16_blob_bytes(B, nref, 0) + 3 * f16_flag_bytes(B);      // sized for either image format
+}
+
+// Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
+// row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
+// tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
+// workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated).
+// g_ms_f16_sparse_cfg: 2 = ms_iterate_d128_f16s_kernel with fp16-head weights (5 MFMAs per block pair; default), 1 = the same with
+// (h, l) weights (6 MFMAs), 3 = the row-major kernel below with fp16-head weights (51.1 vs 46.9 ms: half the copy bytes do not
+// help the sparse schedule with either kind of weights), 0 = ms_iterate_d128_f16t_kernel
+// (row-major-only stage images, transpose reads, 6 buffers: half the copy traffic, and 8 % slower -- 54.6 vs 50.5 ms on the
+// 64-cloud clustered benchmark: the copies are not what holds the sparse kernel)
+int g_ms_f16_sparse_cfg = 2;
+int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                         int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                         float margin, unsigned long long* stats, hipStream_t stream) {
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
+    if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
+    const int cfg = (g_ms_f16_sparse_cfg == 0 || g_ms_f16_sparse_cfg == 3) ? 5 : 0;      // image format of f16_blob_bytes
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16_blob_bytes(B, N, cfg));
+    uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
+    int* flags2 = (int*)(refblob + f16_blob_bytes(B, nrs * 32, cfg));
+    int* lowq = (int*)((uint8_t*)flags2 + f16_flag_bytes(B));           // clouds whose weighted means cancel (heads-only pass)
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    if (g_ms_f16_sparse_cfg == 0 || g_ms_f16_sparse_cfg == 3) {
+        using L = StageLayoutN;
+        constexpr int smem = F16T_NBUF * L::STAGE > F16T_REFGROUP * F16S_REFBYTES ? F16T_NBUF * L::STAGE
+                                                                                 : F16T_REFGROUP * F16S_REFBYTES;
+        static bool attr = false;
+        if (!attr) {
+            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16t_kernel<true, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+        ms_split_n_kernel<false><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_n_kernel<false><<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+        if (g_ms_f16_sparse_cfg == 3) {        // fp16-head weights; flagged clouds again with (h, l) weights
+            ms_iterate_d128_f16t_kernel<true, false><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq);
+            ms_iterate_d128_f16t_kernel<true, true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq);
+        } else {
+            ms_iterate_d128_f16t_kernel<true, true><<<dim3((N + 255) / 256, B), 512, smem, stream>>>(
+                X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+        }
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
+    using L = StageLayout<32>;
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+    ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    if (g_ms_f16_sparse_cfg == 2) {        // heads-only weights; flagged clouds again with (h, l) weights (not counted in stats)
+        ms_iterate_d128_f16s_kernel<true, false><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq);
+        ms_iterate_d128_f16s_kernel<true, true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq);
+    } else
+        ms_iterate_d128_f16s_kernel<true, true><<<dim3((N + 255) / 256, B), 512, F16S_NBUF * L::STAGE, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_ms_set_f16_sparse_config(int cfg) {
+    if (cfg < 0 || cfg > 3) return SED_EINVAL;
+    g_ms_f16_sparse_cfg = cfg;
+    return SED_OK;
+}
+
+extern "C" int sed_ms_set_f16_config(int cfg) {
+    if (cfg < 0 || cfg > 8) return SED_EINVAL;
+    g_ms_f16_cfg = cfg;
+    return SED_OK;
+}

@@ -1,4 +1,4 @@
-"""Bandwidth K-th distance: first sweep on every other vs every fourth key tile (sed_ms_kth_set_sampling) -- time, bit-identity,
+"""Bandwidth K-th distance: first sweep on every other vs every fourth key tile (ops.KTH_SAMPLING -> the `sampling` argument of sed_ms_kth_fused_f32) -- time, bit-identity,
 fallback counts -- on clustered and on unstructured rows, at the script's K and the guard retries' K.   python tools/kth_sampling_ab.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ for name, X in data.items():
     for K in (150, 180, 216):
         res = {}
         for stride in (2, 4):
-            lib.sed_ms_kth_set_sampling(stride)
+            ops.KTH_SAMPLING = stride
             ops.ms_bandwidth(X, K, 0.003); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -23,4 +23,4 @@ for name, X in data.items():
             e1.record(); torch.cuda.synchronize()
             print(f"{name:10s} K {K} stride {stride}: {e0.elapsed_time(e1) / 3:7.2f} ms", flush=True)
         print(f"           identical: {bool(torch.equal(res[2], res[4]))}")
-lib.sed_ms_kth_set_sampling(4)
+ops.KTH_SAMPLING = 0

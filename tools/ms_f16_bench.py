@@ -8,7 +8,7 @@ from sednet_hip import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["f16", "f16i", "f16v1", "f16b", "batched"]
+variants = sys.argv[4].split(",") if len(sys.argv) > 4 else ["f16", "f16c", "batched"]
 g = torch.Generator().manual_seed(0)
 cent = torch.nn.functional.normalize(torch.randn(B, 14, 128, generator=g), dim=2)
 X = cent[:, torch.arange(N) % 14] + 0.02 * torch.randn(B, N, 128, generator=g)

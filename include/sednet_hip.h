@@ -101,10 +101,14 @@ int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const fl
  *   exact fp32 kernel on the device.
  * weight_digits: fp16 digits of the kernel weights in the split-fp16 second product: 0 / 1 = fp16 heads, consistently in
  *   numerator and row sum (5 MFMAs per 32 x 32 x 128 block pair; clouds in which a weighted mean nearly cancels are flagged on the
- *   device and redone with 2 digits), 2 = (h, l) pairs everywhere (6 MFMAs; fp32-equivalent). */
+ *   device and redone with 2 digits), 2 = (h, l) pairs everywhere (6 MFMAs; fp32-equivalent).
+ * wave_queries: query rows per wave of the split-fp16 dense kernel: 0 = default, 32 = 8-wave workgroups (two waves per SIMD,
+ *   256 registers each), 64 = 4-wave workgroups (one wave per SIMD with the whole 512-register file: every key operand read
+ *   from LDS feeds two query groups). Same MFMA order per accumulator: the two forms return the same bits. */
 typedef struct sed_ms_options {
     int schedule;
     int weight_digits;
+    int wave_queries;
 } sed_ms_options_t;
 /* Same, with a caller-owned workspace of sed_ms_iterate_workspace_bytes(B, N, d, opt) bytes (0 = none needed). */
 size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options_t* opt);

@@ -831,10 +831,10 @@ size_t ms_f16_chunked_workspace_bytes(int B, int N);
 int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
                                                           int, int*, hipStream_t),
-                          int digits, hipStream_t stream);
+                          int digits, int wq, hipStream_t stream);
 size_t ms_f16_workspace_bytes(int B, int N);
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
-                  int** flags_out, int digits, hipStream_t stream);
+                  int** flags_out, int digits, int wq, hipStream_t stream);
 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
@@ -849,11 +849,14 @@ static int ms_combine_launch(const float* partO, const float* partS, const float
 }
 
 // Per-call options (include/sednet_hip.h: sed_ms_options_t); NULL = defaults. The library keeps no state between calls.
-struct sed_ms_options { int schedule; int weight_digits; };
+struct sed_ms_options { int schedule; int weight_digits; int wave_queries; };
+constexpr int MS_DEFAULT_WAVE_QUERIES = 64;     // same bits as 32; half the LDS reads per MFMA, no scratch (ms_iterate_f16.hip)
 static int opt_schedule(const sed_ms_options* o) { return o ? o->schedule : 0; }
 static int opt_digits(const sed_ms_options* o) { return (o && o->weight_digits == 2) ? 2 : 1; }
+static int opt_wq(const sed_ms_options* o) { return (o && o->wave_queries) ? o->wave_queries : MS_DEFAULT_WAVE_QUERIES; }
 static bool opt_valid(const sed_ms_options* o) {
-    return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2);
+    return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2 &&
+                  (o->wave_queries == 0 || o->wave_queries == 32 || o->wave_queries == 64));
 }
 
 // which schedule sed_ms_iterate_ws_f32 runs for this shape when given the workspace it asks for:
@@ -885,7 +888,7 @@ extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* b
 extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                      void* workspace, size_t workspace_bytes, const sed_ms_options* opt, hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !opt_valid(opt)) return SED_EINVAL;
-    const int forced = opt_schedule(opt), digits = opt_digits(opt);
+    const int forced = opt_schedule(opt), digits = opt_digits(opt), wq = opt_wq(opt);
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     dim3 grid((N + 127) / 128, B), block(256);
     const int S = ms_chunks(N);
@@ -895,9 +898,9 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     if (plan == MS_F16_CHUNKED && workspace_bytes < ms_f16_chunked_workspace_bytes(B, N)) plan = MS_F16;
     if (plan == MS_F16 || plan == MS_F16_CHUNKED) {
         int* flags = nullptr;
-        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, digits, stream)
+        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, digits, wq, stream)
                                       : ms_f16_chunked_launch(B, N, iters, bw, X, newX, workspace, &flags,
-                                                              ms_combine_launch, digits, stream);
+                                                              ms_combine_launch, digits, wq, stream);
         if (rc != SED_OK) return rc;
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud

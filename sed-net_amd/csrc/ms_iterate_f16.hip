@@ -566,6 +566,9 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
 // With one wave per SIMD nothing hides a wave's latencies but its own software pipeline: the exponentials of block n sit
 // between the MFMAs of block n + 1's first product (<= 5 single-issue instructions per MFMA gap), operands travel through the
 // same register ring RD steps ahead, one barrier per block.
+#ifndef F16W_RING_DISTANCE
+#define F16W_RING_DISTANCE 1
+#endif
 template <bool CHUNKED = false, bool PL = true>
 __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
     using L = StageLayoutN;
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int NBUF = 3;
-    constexpr int RD = F16Q_RING_DISTANCE;
+    constexpr int RD = F16W_RING_DISTANCE;             // one step ahead = 6 / 4 MFMAs (192 / 128 matrix cycles) per operand pair
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
     const int tid = threadIdx.x;
@@ -737,14 +740,17 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
     }
 
-    for (int n = 0; n < total; ++n) {
+    // One block of the pipeline. HAS_NEXT: the block is followed by another one of the same sweep (whose first product runs here,
+    // under this block's weights). The blocks of a sweep form the INNER loop and the row update sits between sweeps, outside it:
+    // with everything in one flat loop the register allocator weighed the row update like the hot path and spilled inside it.
+    int n = 0;                                            // blocks done (the DMA runs three blocks ahead of it)
+    auto block = [&](auto has_next_c) __attribute__((always_inline)) {
+        constexpr bool has_next = decltype(has_next_c)::value;
         const uint8_t* base = lds + buf * STAGE;
         const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
         const uint8_t* nbase = lds + nbuf * STAGE;
         const uint8_t* n2base = lds + (nbuf == NBUF - 1 ? 0 : nbuf + 1) * STAGE;
         const int key0 = st_cur * 32;
-        const bool sweep_end = !CHUNKED && (fwd_cur ? st_cur == nst - 1 : st_cur == 0);
-        const bool has_next = n + 1 < total && !sweep_end;
         const bool tail = key0 + 32 > N;
         refresh_offsets();
 
@@ -792,7 +798,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (has_next) {
+        if constexpr (has_next) {
             if (tail) phase1(std::true_type{});
             else phase1(std::false_type{});
         } else {
@@ -837,20 +843,36 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
 
         advance(st_cur, fwd_cur);
         buf = nbuf;
-        if (!sweep_end) {
+        ++n;
+        if constexpr (has_next) {
             s_cur[0] = s_next[0];
             s_cur[1] = s_next[1];
-            continue;
         }
+    };
+
+    const int nsweep = CHUNKED ? 1 : iters, len = CHUNKED ? s1 - s0 : nst;
+    for (int it = 0; it < nsweep; ++it) {
+#ifdef F16W_PIN_QL
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(ql[g][t]));
+#endif
+        for (int i = 0; i + 1 < len; ++i) block(std::true_type{});
+        if (len > 0) block(std::false_type{});
+        if (CHUNKED) break;
         // ---- end of a sweep: row update (mean_shift.py:70-77), one query group after the other
         bool low = false;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const float rs = rsum[g] + xor32(rsum[g]);
             const float Dinv = UNSCALE_O / rs;
-            float qacc[4][16];
+            // (one feature tile at a time: 16 values of the current Q live beside the accumulators, not 64 -- the kernel must not
+            // spill; the additions into n2 keep the order of the 8-wave kernel: tile by tile, register by register)
+            float n2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c) {
+                float qacc[16];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -859,33 +881,37 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                         const float e1 = ((float)qh[g][2 * c + j][4 + u] + (float)ql[g][2 * c + j][4 + u]) * UNSCALE_Q;
                         const float keep = hi ? e1 : e0, send = hi ? e0 : e1;
                         const float recv = __shfl_xor(send, 32, 64);
-                        qacc[c][8 * j + u] = hi ? recv : keep;
-                        qacc[c][8 * j + 4 + u] = hi ? keep : recv;
+                        qacc[8 * j + u] = hi ? recv : keep;
+                        qacc[8 * j + 4 + u] = hi ? keep : recv;
                     }
-            float n2 = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float q = qacc[c][r];
+                    const float q = qacc[r];
                     const float m = o[g][c][r] * Dinv - q;
                     const float nq = q + m;
                     o[g][c][r] = nq;
                     n2 += nq * nq;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             n2 += xor32(n2);
             const float nrm = sqrtf(n2);
             if (nrm < 0.5f) low = true;
-            if (n == total - 1) {
-                if (qrow[g] < N) {
-                    float* out = newX + ((size_t)cloud * N + qrow[g]) * 128;
+            if (n == total) {
+                // (row index and output address recomputed from a lane id the compiler cannot hoist: addresses formed at kernel
+                // entry would live -- and spill -- across the whole launch)
+                int l;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                const int qr = bx * 256 + wave * 64 + g * 32 + (l & 31), hl = l >> 5;
+                if (qr < N) {
+                    float* out = newX + ((size_t)cloud * N + qr) * 128;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
                             f32x4 v = {o[g][c][4 * q4] / nrm, o[g][c][4 * q4 + 1] / nrm, o[g][c][4 * q4 + 2] / nrm,
                                        o[g][c][4 * q4 + 3] / nrm};
-                            *(f32x4*)(out + 32 * c + 8 * q4 + 4 * hi) = v;
+                            *(f32x4*)(out + 32 * c + 8 * q4 + 4 * hl) = v;
                         }
                 }
             } else {
@@ -912,7 +938,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
             }
         }
         if (!PL && lowq != nullptr && low) lowq[cloud] = 1;
-        if (n != total - 1) plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
+        if (n != total) plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
     }
     if (CHUNKED) {
 #pragma unroll
@@ -1385,6 +1411,14 @@ static int f16r_attr() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
     attr = true;
     return SED_OK;
 }
@@ -1392,7 +1426,7 @@ static int f16r_attr() {
 // one launch, all iterations; flags live behind the stage images; *flags_out = the per-cloud "rows not unit" flags the exact
 // fp32 kernel reads
 int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace, int** flags_out,
-                  int digits, hipStream_t stream) {
+                  int digits, int wq, hipStream_t stream) {
     using L = StageLayoutN;
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes_n(B, N));
@@ -1405,7 +1439,16 @@ int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, floa
     const int nst = (N + 31) / 32;
     const dim3 grid((N + 255) / 256, B);
     ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
-    if (digits == 2) {
+    if (wq == 64) {              // 64 queries per wave: 4-wave workgroups, one wave per SIMD (same bits)
+        if (digits == 2) {
+            ms_iterate_d128_f16w_kernel<false, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters);
+        } else {
+            ms_iterate_d128_f16w_kernel<false, false><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters,
+                                                                                           nullptr, nullptr, nullptr, lowq);
+            ms_iterate_d128_f16w_kernel<false, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters,
+                                                                                          nullptr, nullptr, nullptr, lowq);
+        }
+    } else if (digits == 2) {
         ms_iterate_d128_f16r_kernel<false, true><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters);
     } else {
         ms_iterate_d128_f16r_kernel<false, false><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters,
@@ -1437,7 +1480,7 @@ size_t ms_f16_chunked_workspace_bytes(int B, int N) {
 int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
                                                           int, int*, hipStream_t),
-                          int digits, hipStream_t stream) {
+                          int digits, int wq, hipStream_t stream) {
     using L = StageLayoutN;
     const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
     uint8_t* blob = (uint8_t*)workspace;
@@ -1455,7 +1498,13 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
     ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
-        if (heads)
+        if (wq == 64 && heads)
+            ms_iterate_d128_f16w_kernel<true, false><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
+                                                                                         partS);
+        else if (wq == 64)
+            ms_iterate_d128_f16w_kernel<true, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
+                                                                                        partS);
+        else if (heads)
             ms_iterate_d128_f16r_kernel<true, false><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
                                                                                          partS);
         else
@@ -1465,9 +1514,14 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
         const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, heads ? lowq : nullptr, stream);
         if (rc != SED_OK) return rc;
     }
-    if (heads && iters > 0)                           // flagged clouds again, (h, l) weights, all iterations in one launch
-        ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    if (heads && iters > 0) {                         // flagged clouds again, (h, l) weights, all iterations in one launch
+        if (wq == 64)
+            ms_iterate_d128_f16w_kernel<false, true><<<dim3((N + 255) / 256, B), 256, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+        else
+            ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
+                X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+    }
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -19,7 +19,7 @@ P = c_void_p  # every device pointer / stream travels as void*
 
 class MsOptions(ctypes.Structure):
     """sed_ms_options_t (include/sednet_hip.h): per-call options of the mean-shift iteration entry points."""
-    _fields_ = [("schedule", c_int), ("weight_digits", c_int)]
+    _fields_ = [("schedule", c_int), ("weight_digits", c_int), ("wave_queries", c_int)]
 
 
 OPT = ctypes.POINTER(MsOptions)

@@ -204,6 +204,7 @@ MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
 # captured HIP graphs (pipeline.py) can be keyed on it.
 _MS_VARIANT = "auto"
 _MS_WEIGHT_DIGITS = 1
+MS_WAVE_QUERIES = 0      # query rows per wave of the dense split-fp16 kernel: 0 = library default, 32, 64 (same bits)
 CONFIG_EPOCH = 0
 _MS_SCHEDULES = {"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16c": 5}
 
@@ -214,7 +215,7 @@ def config_changed():
 
 
 def _ms_options():
-    return _lib.MsOptions(_MS_SCHEDULES[_MS_VARIANT], _MS_WEIGHT_DIGITS)
+    return _lib.MsOptions(_MS_SCHEDULES[_MS_VARIANT], _MS_WEIGHT_DIGITS, MS_WAVE_QUERIES)
 
 
 def ms_set_weight_digits(digits):

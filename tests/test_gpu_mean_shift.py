@@ -166,6 +166,32 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
 
+def test_wide_wave_kernel_is_bit_identical(T):
+    """The dense split-fp16 kernel exists with 32 queries per wave (8-wave workgroups, two waves per SIMD) and with 64 (4-wave
+    workgroups, one wave per SIMD and its whole 512-register file; the default): same MFMA order per accumulator, same key order,
+    same row update -- the same bits, in the one-launch and the key-chunked form, with one and with two weight digits, on a
+    ragged last stage, including a cloud whose cancelling means send it through the two-digit redo pass."""
+    from sednet_hip import ops, synth
+    Xs = np.stack([synth.clustered_embedding(N=4999, d=128, n_clusters=9 + c, sigma=0.02, seed=140 + c)[0] for c in range(2)])
+    rnd = T.nn.functional.normalize(T.randn(1, 4999, 128, generator=T.Generator().manual_seed(9)), dim=2)
+    X = T.cat([T.from_numpy(Xs), rnd]).cuda().contiguous()
+    bw = ops.ms_bandwidth(X, 75, 0.003)
+    try:
+        for v in ("f16", "f16/2", "f16c", "f16c/2"):
+            for iters in (1, 7):
+                set_schedule(v)
+                ops.MS_WAVE_QUERIES = 32
+                a = ops.ms_iterate(X, bw, iters)
+                ops.MS_WAVE_QUERIES = 64
+                b = ops.ms_iterate(X, bw, iters)
+                assert T.equal(a, b), (v, iters)
+                ops.MS_WAVE_QUERIES = 0
+                assert T.equal(ops.ms_iterate(X, bw, iters), b)         # the default is the 64-query form
+    finally:
+        ops.MS_WAVE_QUERIES = 0
+        reset_schedule()
+
+
 def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
     """The default kernels feed the weights into the second product as fp16 heads; normalising a weighted mean of norm |o|
     amplifies that rounding by 1 / |o|. Unstructured rows under a bandwidth that spans the cloud have |o| ~ 1 / sqrt(N): the

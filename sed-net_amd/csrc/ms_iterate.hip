@@ -852,7 +852,7 @@ static int ms_combine_launch(const float* partO, const float* partS, const float
 struct sed_ms_options { int schedule; int weight_digits; int wave_queries; };
 constexpr int MS_DEFAULT_WAVE_QUERIES = 64;     // same bits as 32; half the LDS reads per MFMA, no scratch (ms_iterate_f16.hip)
 static int opt_schedule(const sed_ms_options* o) { return o ? o->schedule : 0; }
-static int opt_digits(const sed_ms_options* o) { return (o && o->weight_digits == 2) ? 2 : 1; }
+static int opt_digits(const sed_ms_options* o) { return (o && o->weight_digits == 1) ? 1 : 2; }     // 0 = default = 2
 static int opt_wq(const sed_ms_options* o) { return (o && o->wave_queries) ? o->wave_queries : MS_DEFAULT_WAVE_QUERIES; }
 static bool opt_valid(const sed_ms_options* o) {
     return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2 &&
@@ -1007,7 +1007,7 @@ extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, con
     if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
     int* flags = nullptr;
     const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
-                                        margin, (unsigned long long*)stats, weight_digits == 2 ? 2 : 1, stream);
+                                        margin, (unsigned long long*)stats, weight_digits == 1 ? 1 : 2, stream);
     if (rc != SED_OK) return rc;
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
     static bool attr_fb = false;

@@ -864,7 +864,10 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         // ---- end of a sweep: row update (mean_shift.py:70-77), one query group after the other
         bool low = false;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int gi = 0; gi < 2; ++gi) {
+            // (the two groups are independent; the order only steers hipcc 7.2's register allocator: with this one both
+            // instantiations come out at 0 spilled registers / 0 bytes of scratch, with the other one 24 resp. 48 are spilled)
+            const int g = PL ? 1 - gi : gi;
             const float rs = rsum[g] + xor32(rsum[g]);
             const float Dinv = UNSCALE_O / rs;
             // (one feature tile at a time: 16 values of the current Q live beside the accumulators, not 64 -- the kernel must not
@@ -936,6 +939,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                     for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
                 rsum[g] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);             // one query group after the other: nothing of the second is started early
         }
         if (!PL && lowq != nullptr && low) lowq[cloud] = 1;
         if (n != total) plain_first_product(lds + buf * STAGE);          // first block of the next sweep, new Q
@@ -960,15 +964,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         }
         return;
     }
-    if (iters == 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-            if (qrow[g] < N) {
-                float* out = newX + ((size_t)cloud * N + qrow[g]) * 128;
-                const float* in = Xc + (size_t)qrow[g] * 128;
-                for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
-            }
-    }
+    // (iters == 0 never reaches this kernel: sed_ms_iterate_ws_f32 only plans the split-fp16 schedules for iters > 0)
 }
 
 // ------------------------------------------------------------------------------------------------------------

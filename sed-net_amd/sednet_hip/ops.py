@@ -203,7 +203,7 @@ MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
 # libsedhip.so itself keeps none. CONFIG_EPOCH counts changes of any kernel-selection switch of this module, so that
 # captured HIP graphs (pipeline.py) can be keyed on it.
 _MS_VARIANT = "auto"
-_MS_WEIGHT_DIGITS = 1
+_MS_WEIGHT_DIGITS = 2
 MS_WAVE_QUERIES = 0      # query rows per wave of the dense split-fp16 kernel: 0 = library default, 32, 64 (same bits)
 CONFIG_EPOCH = 0
 _MS_SCHEDULES = {"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16c": 5}
@@ -219,9 +219,10 @@ def _ms_options():
 
 
 def ms_set_weight_digits(digits):
-    """fp16 digits of the kernel weights in the split-fp16 mean-shift kernels' second product: 1 (default; fp16 heads only,
-    consistently in numerator and row sum: 5 MFMAs per block pair, rows within ~5e-7 of the exact fp32 kernel per iteration) or
-    2 ((h, l) pairs, 6 MFMAs, fp32-equivalent: ~1e-7; 12 % slower). Applies to the dense and the block-sparse schedule."""
+    """fp16 digits of the kernel weights in the split-fp16 mean-shift kernels' second product: 2 (default; (h, l) pairs, 6 MFMAs
+    per block pair, fp32-equivalent) or 1 (fp16 heads only, consistently in numerator and row sum: 5 MFMAs, 14 % faster, rows
+    ~10 x further from the exact fp32 kernel -- on a trained network's embedding 0.2 % of the labels move). Applies to the dense and
+    the block-sparse schedule."""
     global _MS_WEIGHT_DIGITS
     if digits not in (1, 2):
         raise ValueError("digits must be 1 or 2")
@@ -523,18 +524,34 @@ def reverse_graph(idx):
     return rptr, order.int().contiguous()
 
 
+EDGE_WS_BYTES = 8 << 30     # upper bound for the per-edge workspace of the deterministic EdgeConv backward; larger batches are
+                            # processed in cloud chunks (weight gradients of the chunks added in chunk order: still deterministic)
+
+
 def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=None, bf16=False):
     """-> (dW1t [C,Cout], dW2t [C,Cout], dx [B,N,ldx] or None)."""
     B, N, ldx = x.shape
     k = idx.shape[2]
     Cout = W1t.shape[1]
     dev = x.device
+    det = DETERMINISTIC_BWD if deterministic is None else deterministic
+    if need_dx and det and Cout <= 128 and B > 1:
+        per_cloud = lib.sed_edgeconv_bwd_edge_ws_bytes(1, N, C, 32 if bf16 else Cout, k)
+        bc = max(1, min(B, EDGE_WS_BYTES // max(per_cloud, 1)))
+        if bc < B:                                          # (ADVICE r2: 21 GB at 32 x 10 000, k = 64, Cout = 128 in one piece)
+            dW1t = dW2t = None
+            dxs = []
+            for b0 in range(0, B, bc):
+                sl = slice(b0, min(B, b0 + bc))
+                a, b_, d = edgeconv_bwd(x[sl], C, idx[sl].contiguous(), W1t, W2t, G, S[sl], jsel[sl], ak[sl], need_dx, det, bf16)
+                dW1t, dW2t = (a, b_) if dW1t is None else (dW1t + a, dW2t + b_)
+                dxs.append(d)
+            return dW1t, dW2t, torch.cat(dxs, 0)
     dW1t = torch.empty((C, Cout), dtype=torch.float32, device=dev)
     dW2t = torch.empty((C, Cout), dtype=torch.float32, device=dev)
     dx = torch.zeros((B, N, ldx), dtype=torch.float32, device=dev) if need_dx else None
     nb = lib.sed_edgeconv_bwd_partials_bytes(B, N, C, Cout)
     part = _bytes(nb, dev)
-    det = DETERMINISTIC_BWD if deterministic is None else deterministic
     rptr = redge = ews = None
     nws = 0
     if need_dx and det and Cout <= 128:
@@ -580,6 +597,14 @@ def gemm(A, B, transA=False, transB=False, bf16=None):
     assert (B.shape[1] if transB else B.shape[0]) == K and A.stride(1) == 1 and B.stride(1) == 1
     assert A.is_cuda and B.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32
     p2 = lambda t: _lib.c_void_p(t.data_ptr())                     # 2-D row-strided views
+
+    def _aligned(t):                  # the kernel reads rows as float4s: row stride % 4 == 0 (e.g. a K = 6 weight);
+        if t.stride(0) % 4 == 0:      # otherwise a zero-padded copy with the same logical shape
+            return t
+        buf = torch.zeros((t.shape[0], (t.shape[1] + 3) // 4 * 4), dtype=torch.float32, device=t.device)
+        buf[:, :t.shape[1]] = t
+        return buf[:, :t.shape[1]]
+    A, B = _aligned(A), _aligned(B)
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     ns = lib.sed_gemm_splits(M, N, K)
     ws = torch.empty((ns * M * N,), dtype=torch.float32, device=A.device) if ns > 1 else None

@@ -172,6 +172,31 @@ def closed_form_state_dict(salt=0):
     return sd
 
 
+_TRAINED = {}
+
+
+def trained_weights_path():
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(os.path.dirname(here)), "tests", "golden", "w_trained.npz")
+
+
+def trained_state_dict(role):
+    """State dict of a network TRAINED by the reference's own training step on synthetic clouds (tests/golden/train_weights.py
+    ran /root/reference/train_sed_net.py:233-283's loss under the CPU shim; the arrays are a data fixture). role: "type" or
+    "inst" -- two snapshots of the run, like the script's two checkpoints (generate_predictions_aug.py:142-167). Unlike the
+    closed-form weights these separate the segments of a synthetic cloud: >= 3 primitive types and >= 8 mean-shift clusters per
+    cloud, which is what the end-to-end fixtures (f_e2e, f_10k) and bench.py's headline need."""
+    if role not in ("type", "inst"):
+        raise ValueError(role)
+    if not _TRAINED:
+        with np.load(trained_weights_path()) as z:
+            for k in z.files:
+                r, name = k.split("/", 1)
+                _TRAINED.setdefault(r, {})[name] = z[k]
+    return dict(_TRAINED[role])
+
+
 # ---------------------------------------------------------------------------------------------
 # embeddings for the clustering stage in isolation
 # ---------------------------------------------------------------------------------------------

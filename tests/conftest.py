@@ -39,3 +39,38 @@ def assert_close_up_to_graph_ties(got, ref, atol, max_frac=5e-4, loose=5e-2, wha
     assert bad.mean() <= max_frac, f"{what}: {bad.sum()} / {bad.size} elements beyond {atol} (max err {err.max():.3e})"
     assert err.max() <= loose, f"{what}: max err {err.max():.3e} beyond the near-tie allowance {loose}"
     return float(bad.mean()), float(err.max())
+
+
+def label_agreement(got, ref, margin=None, tie=None):
+    """Integer outputs against the reference's (north_star: "bit-exact segment indices after label canonicalisation", "seg-IoU
+    within 1e-3"): cluster ids are matched one to one (Hungarian on the contingency table -- which converged row represents a
+    cluster in nms, hence the id, depends on last-ulp noise: mean_shift.py:149,171), then -> dict(rate = share of points with the
+    matched label, mismatches = their indices, iou = mean IoU of the matched segments, n_got / n_ref = cluster counts,
+    undecided = mismatching points whose decision margin in the reference (`margin`, per point) is NOT below `tie`: a point
+    the reference itself puts within rounding distance of two clusters may legitimately fall on the other side)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    got, ref = np.asarray(got).astype(np.int64).ravel(), np.asarray(ref).astype(np.int64).ravel()
+    ug, gi = np.unique(got, return_inverse=True)
+    ur, ri = np.unique(ref, return_inverse=True)
+    M = np.zeros((ug.size, ur.size))
+    np.add.at(M, (gi, ri), 1)
+    r, c = linear_sum_assignment(-M)
+    to_ref = np.full(ug.size, -1)
+    to_ref[r] = c
+    same = to_ref[gi] == ri
+    inter = M[r, c]
+    union = M[r].sum(1) + M[:, c].sum(0) - inter
+    iou = float((inter / np.maximum(union, 1)).sum() / max(ug.size, ur.size))
+    bad = np.nonzero(~same)[0]
+    undecided = bad if margin is None else bad[np.asarray(margin, np.float32)[bad] >= tie]
+    return {"rate": float(same.mean()), "mismatches": bad, "undecided": undecided, "iou": iou, "n_got": int(ug.size),
+            "n_ref": int(ur.size)}
+
+
+def seg_iou_delta(got, ref, gt):
+    """north_star's "seg-IoU within 1e-3 of reference": the METRIC -- Hungarian-matched mean segment IoU against the ground truth
+    (src/segment_utils.py:194-242) -- of the device labels minus that of the reference's labels. -> (delta, ours, reference's)"""
+    from src.segment_utils import seg_iou
+    a, b = seg_iou(got, gt), seg_iou(ref, gt)
+    return a - b, a, b

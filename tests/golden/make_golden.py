@@ -74,25 +74,63 @@ def gen_knn():
 
 # ----------------------------------------------------------------------------------------
 def build_ref_model(k, salt):
+    """salt: int -> closed-form weights (sednet_hip.synth); "type" / "inst" -> the TRAINED weights of
+    tests/golden/w_trained.npz (train_weights.py: the reference's own training step on synthetic clouds)."""
     from src.SEDNet import SEDNet
 
     m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
                combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
-    sd = {k_: t(v) for k_, v in synth.closed_form_state_dict(salt).items()}
+    raw = synth.trained_state_dict(salt) if isinstance(salt, str) else synth.closed_form_state_dict(salt)
+    sd = {k_: t(v) for k_, v in raw.items()}
     missing = m.load_state_dict(sd, strict=True)
     m.eval()
     return m
 
 
+def label_margin(Xn, center, labels):
+    """How decided a point's label is in the reference's own terms (mean_shift.py:176-178: labels = argmax_c C_sel X^T):
+    best minus second-best centre similarity, per point."""
+    sim = torch.sort(Xn @ center.T, 1, descending=True)[0]
+    return (sim[:, 0] - sim[:, 1]).numpy().astype(np.float32) if sim.shape[1] > 1 else np.ones(Xn.shape[0], np.float32)
+
+
 def gen_e2e():
-    N, k = 1024, 20                                   # F-E2E at N = 1024
+    """F-E2E (SURVEY section 8(c), N = 1024) through TRAINED weights (the closed-form network collapses to one type and
+    one blob, every integer output of the old fixture was constant): encoder intermediates, the three heads, the type model's
+    argmax with its log-prob margin, and the instance embedding through MeanShift.mean_shift (num_samples = N: K = 15)."""
+    from src.mean_shift import MeanShift
+    N, k = 1024, 20
+    p, n, labels, types = synth.synthetic_cloud(21, N)
+    x = np.concatenate([p, n], 1).T[None].astype(F32)
+    m = build_ref_model(k, salt="inst")
+    mt = build_ref_model(k, salt="type")
+    with torch.no_grad():
+        x4, feats = m.encoder(t(x))
+        emb, logp, _, edges = m(t(x), None, False)
+        logp_t = mt(t(x), None, False)[1][0].numpy()
+    srt = np.sort(logp_t, 0)
+    X = torch.nn.functional.normalize(emb[0].T, p=2, dim=1)
+    np.random.seed(0)
+    _, center, bw, ids = MeanShift().mean_shift(X, N, 0.015, 50)
+    print("f_e2e: types", np.unique(np.argmax(logp_t, 0)), "clusters", int(torch.unique(ids).shape[0]), "bw", float(bw))
+    save("f_e2e", x=x, k=np.int32(k), x4=x4.numpy(), feats=feats.numpy(),
+         embedding=emb.numpy(), log_prob=logp.numpy(), edges=edges.numpy(),
+         types=np.argmax(logp_t, 0).astype(np.int8), types_margin=(srt[-1] - srt[-2]).astype(np.float32),
+         gt_labels=labels.astype(np.int16), gt_types=types.astype(np.int8),
+         labels=ids.numpy().astype(np.int16), bw=bw.numpy(), label_margin=label_margin(X, center, ids))
+
+
+def gen_e2e_closed():
+    """The round-1 F-E2E on closed-form weights (some GroupNorm gammas negative: the min-over-k path of the fused EdgeConv), kept
+    for the activations only -- its integer outputs are degenerate."""
+    N, k = 1024, 20
     p, n, labels, types = synth.synthetic_cloud(21, N)
     x = np.concatenate([p, n], 1).T[None].astype(F32)
     m = build_ref_model(k, salt=1)
     with torch.no_grad():
         x4, feats = m.encoder(t(x))
         emb, logp, _, edges = m(t(x), None, False)
-    save("f_e2e", x=x, k=np.int32(k), salt=np.int32(1), x4=x4.numpy(), feats=feats.numpy(),
+    save("f_e2e_closed", x=x, k=np.int32(k), salt=np.int32(1), x4=x4.numpy(), feats=feats.numpy(),
          embedding=emb.numpy(), log_prob=logp.numpy(), edges=edges.numpy())
 
 
@@ -362,27 +400,16 @@ def gen_chamfer():
 
 # ----------------------------------------------------------------------------------------
 def gen_full10k():
-    """F-10K: BASELINE size through the reference itself. (1) the script's flow on bench cloud 0
+    """F-10K: BASELINE size through the reference itself, TRAINED weights. (1) the script's flow on bench cloud 0 and cloud 1
     (generate_predictions_aug.py:221-236, :365, :380-382): type model -> argmax types, instance model -> unit embedding
-    -> guard_mean_shift(0.015, 50) -> labels; (2) the clustering stage alone on an embedding with realistic structure
-    (unequal clusters, a close pair, bridge points), where label parity is not trivial. Only outputs are stored (labels,
-    types, bandwidths, the log-prob margin for a tie-aware comparison); the inputs are regenerated from sednet_hip.synth,
-    a checksum pins them."""
+    -> guard_mean_shift(0.015, 50) -> labels; (2) the clustering stage alone on an embedding with planted structure
+    (unequal clusters, a close pair, bridge points). Only outputs are stored (labels, types, bandwidths, the margins for a
+    tie-aware comparison); the inputs are regenerated from sednet_hip.synth, a checksum pins them."""
     import time
     from src.mean_shift import MeanShift
     N, k = 10000, 20
-    p, n, _, _ = synth.synthetic_cloud(1234, N)                       # bench.py's cloud 0
-    x = np.concatenate([p, n], 1).T[None].astype(F32)
-    out = {"x_sum": np.float64(x.astype(np.float64).sum()), "x_abs_sum": np.float64(np.abs(x.astype(np.float64)).sum())}
-    t0 = time.time()
-    with torch.no_grad():
-        logp = build_ref_model(k, salt=0)(t(x), None, False)[1][0].numpy()            # [6, N]
-        emb = build_ref_model(k, salt=1)(t(x), None, False)[0][0].T                   # [N, 128]
-    srt = np.sort(logp, 0)
-    out["types"] = np.argmax(logp, 0).astype(np.int8)
-    out["logp_margin"] = (srt[-1] - srt[-2]).astype(np.float16)
-    X = torch.nn.functional.normalize(emb, p=2, dim=1)
     ms = MeanShift()
+    mt, mi = build_ref_model(k, salt="type"), build_ref_model(k, salt="inst")
 
     def guard(Xt, q):
         passes = 0
@@ -392,16 +419,34 @@ def gen_full10k():
             if torch.unique(ids).shape[0] > 49:
                 q *= 1.2
             else:
-                return bw, ids, passes
-    np.random.seed(0)
-    bw, ids, passes = guard(X, 0.015)
-    out["labels"], out["bw"], out["passes"] = ids.numpy().astype(np.int16), bw.numpy(), np.int32(passes)
-    out["emb_row_sum"] = X.double().sum(1).numpy().astype(np.float32)               # digest of the embedding, per point
-    print("script flow: clusters", int(torch.unique(ids).shape[0]), "bw", float(bw), "passes", passes, "%.0fs" % (time.time() - t0))
+                return bw, ids, passes, center
+    out = {}
+    for tag, seed in (("", 1234), ("c1_", 1235)):                       # bench.py's clouds 0 and 1
+        p, n, gl, gt = synth.synthetic_cloud(seed, N)
+        x = np.concatenate([p, n], 1).T[None].astype(F32)
+        out[tag + "x_sum"] = np.float64(x.astype(np.float64).sum())
+        out[tag + "x_abs_sum"] = np.float64(np.abs(x.astype(np.float64)).sum())
+        t0 = time.time()
+        with torch.no_grad():
+            logp = mt(t(x), None, False)[1][0].numpy()            # [6, N]
+            emb = mi(t(x), None, False)[0][0].T                   # [N, 128]
+        srt = np.sort(logp, 0)
+        out[tag + "types"] = np.argmax(logp, 0).astype(np.int8)
+        out[tag + "logp_margin"] = (srt[-1] - srt[-2]).astype(np.float16)
+        X = torch.nn.functional.normalize(emb, p=2, dim=1)
+        np.random.seed(0)
+        bw, ids, passes, center = guard(X, 0.015)
+        out[tag + "labels"], out[tag + "bw"], out[tag + "passes"] = ids.numpy().astype(np.int16), bw.numpy(), np.int32(passes)
+        out[tag + "label_margin"] = label_margin(X, center, ids).astype(np.float16)
+        out[tag + "emb_row_sum"] = X.double().sum(1).numpy().astype(np.float32)               # digest of the embedding, per point
+        out[tag + "gt_labels"], out[tag + "gt_types"] = gl.astype(np.int16), gt.astype(np.int8)
+        print(f"script flow, cloud seed {seed}: types", np.unique(out[tag + "types"]), "type acc %.3f" % (out[tag + "types"] == gt).mean(),
+              "clusters", int(torch.unique(ids).shape[0]), "of", len(np.unique(gl)), "bw", float(bw), "passes", passes,
+              "%.0fs" % (time.time() - t0))
     X2, assign = synth.realistic_embedding(N=N, d=128, n_clusters=14, sigma=0.02, bridge=0.04, seed=7)
     np.random.seed(0)
     t0 = time.time()
-    bw2, ids2, passes2 = guard(t(X2), 0.015)
+    bw2, ids2, passes2, _ = guard(t(X2), 0.015)
     out["r_labels"], out["r_bw"], out["r_passes"] = ids2.numpy().astype(np.int16), bw2.numpy(), np.int32(passes2)
     out["r_x_sum"] = np.float64(X2.astype(np.float64).sum())
     agree = (synth_canon(ids2.numpy()) == synth_canon(assign)).mean()
@@ -529,6 +574,6 @@ def gen_eval():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["knn", "e2e", "ms", "fit", "hpnet", "train", "chamfer", "eval", "cyl", "full10k"]
+    which = sys.argv[1:] or ["knn", "e2e", "e2e_closed", "ms", "fit", "hpnet", "train", "chamfer", "eval", "cyl", "full10k"]
     for w in which:
         globals()["gen_" + w]()

@@ -36,10 +36,11 @@ def test_bandwidth_matches_golden_and_oracle(T, golden):
 
 
 def set_schedule(spec):
-    """"f16", "f16c", "batched", ... optionally "/2" for two weight digits; "sparse[/2]" forces the block-sparse schedule."""
+    """"f16", "f16c", "batched", ... optionally "/1" for the fp16-heads weights (default: two weight digits, fp32-equivalent);
+    "sparse[/1]" forces the block-sparse schedule."""
     from sednet_hip import ops
     name, _, digits = spec.partition("/")
-    ops.ms_set_weight_digits(int(digits) if digits else 1)
+    ops.ms_set_weight_digits(int(digits) if digits else 2)
     if name == "sparse":
         ops.ms_set_variant("auto")
         ops.MS_SPARSE = "on"
@@ -51,7 +52,7 @@ def set_schedule(spec):
 def reset_schedule():
     from sednet_hip import ops
     ops.ms_set_variant("auto")
-    ops.ms_set_weight_digits(1)
+    ops.ms_set_weight_digits(2)
     ops.MS_SPARSE = "auto"
 
 
@@ -65,7 +66,7 @@ def variant(request):
 
 # the shipped schedules: three exact-fp32 ones, the split-fp16 kernel in its one-launch / key-chunked form and the block-sparse
 # kernel, each with one (default) and two weight digits
-SCHEDULES = ["batched", "splitk", "chunked", "f16", "f16c", "f16/2", "f16c/2", "sparse", "sparse/2"]
+SCHEDULES = ["batched", "splitk", "chunked", "f16/1", "f16c/1", "f16", "f16c", "sparse/1", "sparse"]
 
 
 @pytest.mark.parametrize("variant", SCHEDULES, indirect=True)
@@ -113,7 +114,7 @@ def test_mean_shift_end_to_end(T, golden):
 
 def test_iteration_variants_agree_at_full_size(T):
     """The fp32 schedules differ only in summation order, the split-fp16 kernel in how the two products are evaluated
-    ("f16/2": 3 fp16 MFMAs on exact (h, l) splits per product, fp32 accumulation; "f16", the default: the second product with
+    ("f16", the default: 3 fp16 MFMAs on exact (h, l) splits per product, fp32 accumulation; "f16/1": the second product with
     the weights' fp16 heads only, consistently in numerator and row sum): 10 000 points, ragged last tile, 3 clouds."""
     from sednet_hip import ops, synth
     Xs = np.stack([synth.clustered_embedding(N=9973, d=128, n_clusters=9 + c, sigma=0.02, seed=40 + c)[0]
@@ -122,7 +123,7 @@ def test_iteration_variants_agree_at_full_size(T):
     bw = ops.ms_bandwidth(X, 150, 0.003)
     res = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16/2", "f16c", "f16c/2"):
+        for v in ("batched", "splitk", "chunked", "f16/1", "f16", "f16c/1", "f16c"):
             set_schedule(v)
             res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
             single = ops.ms_iterate(X[1:2], bw[1:2], 50).cpu().numpy()
@@ -132,21 +133,21 @@ def test_iteration_variants_agree_at_full_size(T):
     # 50 iterations amplify the rounding differences of points still moving (the golden test allows 1e-5 too)
     np.testing.assert_allclose(res["batched"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["chunked"], res["splitk"], atol=2e-5)
+    np.testing.assert_allclose(res["f16/1"], res["splitk"], atol=2e-5)
     np.testing.assert_allclose(res["f16"], res["splitk"], atol=2e-5)
-    np.testing.assert_allclose(res["f16/2"], res["splitk"], atol=2e-5)
-    np.testing.assert_allclose(res["f16"], res["f16/2"], atol=3e-6)   # fp16-head weights vs (h, l) weights (measured 6e-7)
-    np.testing.assert_allclose(res["f16"], res["f16c"], atol=2e-5)    # key-chunked: partial sums added per chunk
-    np.testing.assert_allclose(res["f16/2"], res["f16c/2"], atol=2e-5)
+    np.testing.assert_allclose(res["f16/1"], res["f16"], atol=3e-6)   # fp16-head weights vs (h, l) weights (measured 6e-7)
+    np.testing.assert_allclose(res["f16/1"], res["f16c/1"], atol=2e-5)    # key-chunked: partial sums added per chunk
+    np.testing.assert_allclose(res["f16"], res["f16c"], atol=2e-5)
     try:                       # the planner's own choice for 3 clouds is the key-chunked form, with either number of digits
-        ops.ms_set_weight_digits(2)
-        np.testing.assert_array_equal(ops._ms_iterate_dense(X, bw, 50).cpu().numpy(), res["f16c/2"])
-    finally:
         ops.ms_set_weight_digits(1)
+        np.testing.assert_array_equal(ops._ms_iterate_dense(X, bw, 50).cpu().numpy(), res["f16c/1"])
+    finally:
+        ops.ms_set_weight_digits(2)
     np.testing.assert_array_equal(ops._ms_iterate_dense(X, bw, 50).cpu().numpy(), res["f16c"])
-    assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16"]).all()
+    assert np.isfinite(res["splitk"]).all() and np.isfinite(res["chunked"]).all() and np.isfinite(res["f16/1"]).all()
     one = {}
     try:
-        for v in ("batched", "splitk", "chunked", "f16", "f16/2"):
+        for v in ("batched", "splitk", "chunked", "f16/1", "f16"):
             set_schedule(v)
             one[v] = ops.ms_iterate(X, bw, 1).cpu().numpy()
     finally:
@@ -160,8 +161,8 @@ def test_iteration_variants_agree_at_full_size(T):
     ref = p @ x64 / p.sum(1, keepdims=True)
     ref /= np.linalg.norm(ref, axis=1, keepdims=True)
     np.testing.assert_allclose(one["splitk"][0][rows], ref, atol=3e-6)
+    np.testing.assert_allclose(one["f16/1"][0][rows], ref, atol=3e-6)
     np.testing.assert_allclose(one["f16"][0][rows], ref, atol=3e-6)
-    np.testing.assert_allclose(one["f16/2"][0][rows], ref, atol=3e-6)
     np.testing.assert_allclose(one["chunked"][0][rows], ref, atol=5e-6)
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
@@ -177,7 +178,7 @@ def test_wide_wave_kernel_is_bit_identical(T):
     X = T.cat([T.from_numpy(Xs), rnd]).cuda().contiguous()
     bw = ops.ms_bandwidth(X, 75, 0.003)
     try:
-        for v in ("f16", "f16/2", "f16c", "f16c/2"):
+        for v in ("f16/1", "f16", "f16c/1", "f16c"):
             for iters in (1, 7):
                 set_schedule(v)
                 ops.MS_WAVE_QUERIES = 32
@@ -204,20 +205,20 @@ def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
     bw = ops.ms_bandwidth(X, 45, 0.003)
     res = {}
     try:
-        for v in ("f16", "f16/2", "f16c", "batched"):
+        for v in ("f16/1", "f16", "f16c/1", "batched"):
             set_schedule(v)
             res[v] = ops.ms_iterate(X, bw, 5).cpu().numpy()
-        set_schedule("f16")
+        set_schedule("f16/1")
         alone = ops.ms_iterate(X[1:2], bw[1:2], 5).cpu().numpy()[0]
     finally:
         reset_schedule()
     for c in (0, 2):                # flagged: exactly the rows of the (h, l)-weights kernel on the same stage images, in every form
-        np.testing.assert_array_equal(res["f16"][c], res["f16/2"][c])
-        np.testing.assert_array_equal(res["f16c"][c], res["f16/2"][c])
-        np.testing.assert_allclose(res["f16"][c], res["batched"][c], atol=2e-5)
-    assert (res["f16"][1] != res["f16/2"][1]).any()                      # not flagged: the heads-only rows ...
-    np.testing.assert_array_equal(res["f16"][1], alone)                  # ... the same as without flagged neighbours
-    np.testing.assert_allclose(res["f16"][1], res["f16/2"][1], atol=2e-6)
+        np.testing.assert_array_equal(res["f16/1"][c], res["f16"][c])
+        np.testing.assert_array_equal(res["f16c/1"][c], res["f16"][c])
+        np.testing.assert_allclose(res["f16/1"][c], res["batched"][c], atol=2e-5)
+    assert (res["f16/1"][1] != res["f16"][1]).any()                      # not flagged: the heads-only rows ...
+    np.testing.assert_array_equal(res["f16/1"][1], alone)                  # ... the same as without flagged neighbours
+    np.testing.assert_allclose(res["f16/1"][1], res["f16"][1], atol=2e-6)
 
 
 def test_split_fp16_falls_back_for_non_unit_rows(T):

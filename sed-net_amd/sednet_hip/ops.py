@@ -197,8 +197,14 @@ def ms_bandwidth(X, K, min_bw=0.003):
 # of the cloud alone, so results do not depend on which clouds share a batch.
 MS_SPARSE = "auto"
 MS_SPARSE_SKIP = -30.0
-MS_SPARSE_MAX_NEAR = 0.3
+# Threshold of the density probe. Round 2 (planted sigma = 0.01 clusters: near fractions ~0.08) used 0.3. A TRAINED network's
+# embeddings are wider -- near fractions 0.17 .. 0.54 on the 64 bench clouds, the kernel still skips 52 % of the first and 61 % of
+# the second products -- and the block-sparse kernel beats the dense one on every one of them (3.9 ms per cloud in a 64-cloud launch
+# against 5.75; tools/trained_sparse_stats.py); splitting a batch into a sparse and a dense launch costs more than the dense
+# kernel could win on the widest clouds (134 + 177 ms against 249 ms for all 64 sparse). Unstructured rows sit at 1.0.
+MS_SPARSE_MAX_NEAR = 0.6
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
+MS_SPARSE_COUNTERS = None       # bench.py: an int64 [5] device tensor the block-sparse kernel adds its visit counts to
 # Options of the iteration kernels. They are the WRAPPER's state, handed to the library with every call (sed_ms_options_t);
 # libsedhip.so itself keeps none. CONFIG_EPOCH counts changes of any kernel-selection switch of this module, so that
 # captured HIP graphs (pipeline.py) can be keyed on it.
@@ -345,6 +351,8 @@ def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
         ev0.record()
     nws = lib.sed_ms_iterate_bounds_f16_workspace_bytes(B, N)
     ws = torch.empty((nws,), dtype=torch.uint8, device=Xs.device)
+    if stats is None:
+        stats = MS_SPARSE_COUNTERS
     check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
                                             ptr(prep["ref"]), ptr(prep["cosalpha"]), float(margin), ptr(ws), nws,
                                             ptr(stats) if stats is not None else None, _MS_WEIGHT_DIGITS, stream()),

@@ -483,9 +483,22 @@ def gen_cyl():
         res = cd.distance_from_cylinder(t(p), [a, c, r], sqrt=True)
         P.append(p); Nn.append(n); off.append(off[-1] + n_pts); SIG.append(sig)
         A.append(a.numpy().ravel()); C.append(c.numpy().ravel()); R.append(float(r)); RES.append(float(res))
+    # the same 24 segments with every coordinate moved to the NEXT fp32 value (1 ulp): how far the reference moves its own
+    # centre / radius under an input perturbation of one rounding (the a13 exception proves itself)
+    A1, C1, R1 = [], [], []
+    for i in range(24):
+        p = np.nextafter(P[i], np.float32(np.inf)).astype(F32)
+        w = np.ones((p.shape[0], 1), F32) + np.finfo(np.float32).eps
+        a, c, r = fit.fit_cylinder_torch(t(p), t(Nn[i]), t(w))
+        A1.append(a.numpy().ravel()); C1.append(c.numpy().ravel()); R1.append(float(r))
+    dc = np.linalg.norm(np.array(C1) - np.array(C), axis=1)
+    print("reference under a 1-ulp input perturbation: |dc| median %.2e max %.2e, |dr| max %.2e, axis max %.2e" %
+          (np.median(dc), dc.max(), np.abs(np.array(R1) - np.array(R)).max(),
+           np.min([np.abs(np.array(A1) - np.array(A)).max(1), np.abs(np.array(A1) + np.array(A)).max(1)], 0).max()))
     save("f_cyl", points=np.concatenate(P), normals=np.concatenate(Nn), offsets=np.array(off, np.int32),
          sigma=np.array(SIG, F32), ref_axis=np.array(A, F32), ref_center=np.array(C, F32), ref_radius=np.array(R, F32),
-         ref_residual=np.array(RES, F32))
+         ref_residual=np.array(RES, F32), ulp_axis=np.array(A1, F32), ulp_center=np.array(C1, F32),
+         ulp_radius=np.array(R1, F32))
 
 
 # ----------------------------------------------------------------------------------------

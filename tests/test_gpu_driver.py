@@ -155,3 +155,74 @@ def test_driver_with_hpnet_stage(tmp_path):
     assert rc == 0
     inst = np.loadtxt(out / "1_inst.txt")
     assert inst.shape == (1200,) and inst.min() == 0
+
+
+def _write_trained_checkpoints(tmp_path):
+    """the two checkpoints of the script (generate_predictions_aug.py:191-198) from the trained-weights fixture; one of them with
+    DataParallel's "module." prefix, which the loader must strip (:192)"""
+    import torch
+    from sednet_hip import synth
+    os.makedirs(tmp_path / "ckpts", exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in synth.trained_state_dict("type").items()}, tmp_path / "ckpts" / "type.pth")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in synth.trained_state_dict("inst").items()},
+               tmp_path / "ckpts" / "inst.pth")
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(CFG.replace('"ckpts/none.pth"', f'"{tmp_path}/ckpts/type.pth"').replace('"ckpts/none2.pth"', f'"{tmp_path}/ckpts/inst.pth"'))
+    return cfg
+
+
+def test_driver_at_contract_size_against_the_reference(tmp_path, golden):
+    """generate_predictions.main at N = 10 000 with real checkpoints -- the trained weights written as .pth
+    files, one with the "module." prefix -- on bench clouds 0 and 1: the three output files per cloud, and their contents against
+    the REFERENCE's outputs for the same clouds (f_10k.npz: types from the type checkpoint, instance labels from the instance
+    checkpoint through guard_mean_shift)."""
+    from conftest import label_agreement
+    import generate_predictions as gp
+    g = golden("f_10k")
+    cfg = _write_trained_checkpoints(tmp_path)
+    out = tmp_path / "out"
+    rc = gp.main([str(cfg), "Save", "no_multi_vote", "no_fold5drop", "--synthetic", "2", "--points", "10000", "--batch", "2",
+                  "--out", str(out)])
+    assert rc == 0
+    for cid, tag in (("0", ""), ("1", "c1_")):
+        inst = np.loadtxt(out / f"{cid}_inst.txt").astype(np.int64)
+        types = np.loadtxt(out / f"{cid}_type.txt").astype(np.int64)
+        edge = np.loadtxt(out / f"{cid}_edge.txt", delimiter=";")
+        assert inst.shape == (10000,) and types.shape == (10000,) and edge.shape == (10000, 2)
+        np.testing.assert_allclose(edge.sum(1), 1.0, atol=2e-4)                      # softmax rows, %0.4f
+        bad = types != g[tag + "types"]
+        assert bad.mean() < 2e-3 and (g[tag + "logp_margin"].astype(np.float32)[bad] < 2e-3).all()
+        a = label_agreement(inst, g[tag + "labels"], g[tag + "label_margin"].astype(np.float32), tie=5e-3)
+        assert a["n_got"] == a["n_ref"] and a["rate"] >= 0.999 and a["undecided"].size == 0, a
+
+
+def test_tta_at_contract_size_matches_oracle(tmp_path):
+    """multi_vote + fold5drop at N = 10 000 (generate_predictions_aug.py:307-362: two flips x (the cloud + five 8 000-point
+    subsets)) through the trained type model, against the oracle doing the same augmentation (12 CPU forwards)."""
+    import torch
+    import generate_predictions as gp
+    from oracle import backbone
+    from sednet_hip import synth
+    from src.SEDNet import SEDNet
+    N, k = 10000, 20
+    x, _, _ = synth.batch_clouds(1, N, seed0=1234)
+    params = synth.trained_state_dict("type")
+    m = SEDNet(embedding=True, emb_size=128, primitives=True, num_primitives=6, mode=5, num_channels=6,
+               combine_label_prim=True, edge_module=True, late_fusion=True, nn_nb=k)
+    m.load_state_dict({n: torch.from_numpy(v) for n, v in params.items()})
+    m = m.cuda().eval()
+    got = gp.type_log_prob(m, torch.from_numpy(x).cuda(), True, True).cpu().numpy()
+    ref = 0
+    for d in ((1, 1, 1), (-1, 1, -1)):
+        xr = x * np.array(d * 2, np.float32).reshape(1, 6, 1)
+        cur = backbone.sednet_forward(params, xr, k)[1]
+        tot = np.zeros_like(cur)
+        for i in range(N // 2000):
+            keep = np.ones(N, bool); keep[i * 2000:(i + 1) * 2000] = False
+            tot[:, :, keep] += backbone.sednet_forward(params, np.ascontiguousarray(xr[:, :, keep]), k)[1]
+        ref = ref + cur + tot
+    err = np.abs(got - ref)          # sums of 10 log-probabilities; a kNN near-tie swap moves an isolated point by a few 1e-3
+    assert np.quantile(err, 0.99) < 5e-3 and np.quantile(err, 0.999) < 5e-2 and err.max() < 0.5, (np.quantile(err, 0.999), err.max())
+    srt = np.sort(ref[0], 0)
+    differ = got[0].argmax(0) != ref[0].argmax(0)
+    assert differ.mean() < 2e-3 and ((srt[-1] - srt[-2])[differ] < 2e-2).all()       # only where the oracle's top two tie

@@ -16,20 +16,24 @@ def dev(T, a):
     return T.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def check_idx(got, ref, score, k):
+def check_idx(got, ref, score, k, scale=None, min_same=0.95):
     """rows must agree as ordered lists except where fp32 near-ties make the order ambiguous; on
-    unambiguous rows the neighbour sets must agree exactly."""
+    unambiguous rows the neighbour sets must agree exactly. scale [rows]: magnitude of the terms the score is a difference of
+    (|x_i|^2 + |x_j|^2 for the feature metric: -|x_i|^2 + 2 x_i.x_j - |x_j|^2 cancels, its fp32 error -- in the reference's
+    evaluation as much as in any other -- is relative to THEM, not to the small distance that is left)."""
     srt = -np.sort(-score, axis=-1)[:, :k + 1]
-    ambiguous = (np.abs(np.diff(srt, axis=1)) <= 2e-5 * np.maximum(1.0, np.abs(srt[:, 1:]))).any(1)
+    mag = np.maximum(1.0, np.abs(srt[:, 1:])) if scale is None else np.maximum(np.maximum(1.0, np.abs(srt[:, 1:])), scale[:, None])
+    ambiguous = (np.abs(np.diff(srt, axis=1)) <= 2e-5 * mag).any(1)
     same = (got == ref).all(1)
     assert (same | ambiguous).all(), f"{(~(same | ambiguous)).sum()} rows differ without a near-tie"
-    assert same.mean() > 0.95
+    assert same.mean() > min_same
     sets = np.array([set(a) == set(b) for a, b in zip(got, ref)])
     assert sets[~ambiguous].all()
     # every returned index must be a true k-NN up to the tie tolerance
     kth = srt[:, k - 1]
     picked = np.take_along_axis(score, got, axis=1)
-    assert (picked >= (kth - 2e-5 * np.maximum(1.0, np.abs(kth)))[:, None]).all()
+    kmag = np.maximum(1.0, np.abs(kth)) if scale is None else np.maximum(np.maximum(1.0, np.abs(kth)), scale)
+    assert (picked >= (kth - 2e-5 * kmag)[:, None]).all()
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -180,3 +184,34 @@ def test_key_chunked_second_sweeps_do_not_change_results(T):
             bw = ops.ms_bandwidth(X, K, 0.003)
             assert T.equal(ops.ms_bandwidth(X[:1].contiguous(), K, 0.003), bw[:1])
             assert T.equal(ops.ms_bandwidth(X[2:4].contiguous(), K, 0.003), bw[2:4])
+
+
+@pytest.mark.parametrize("metric,k", [("pn", 20), ("pn", 64), ("feat", 20), ("feat", 64)])
+def test_every_mismatch_at_10k_is_a_near_tie(T, metric, k):
+    """N = 10 000: not a match RATE but the strict statement -- on 512 sampled rows EVERY difference between the
+    device's neighbour list and the stable fp32 argsort of the oracle's scores sits on a near-tie (|delta score| <= 2e-5 relative,
+    where torch.topk's own order is unspecified), unambiguous rows have identical neighbour sets, and every returned index is a
+    true k-NN up to that tolerance. Both metrics (xyz x normal on a synthetic cloud; L2 on 64-d features of the trained
+    encoder's first layer), k = 20 and the reference default k = 64."""
+    from oracle import graph
+    from sednet_hip import ops, synth
+    from src.PointNet import knn, knn_points_normals
+    N = 10000
+    x, _, _ = synth.batch_clouds(1, N, seed0=1234)
+    rows = np.random.default_rng(k).choice(N, 512, replace=False)
+    scale = None
+    if metric == "pn":
+        got = knn_points_normals(dev(T, x), k, k, 1.0)[0].cpu().numpy()
+        score = graph.knn_points_normals_scores(x[0])[rows]
+    else:
+        from test_gpu_backbone import build
+        with T.no_grad():
+            feats = build(T, 20, "inst").encoder(dev(T, x))[1][:, :64].contiguous()        # x1 = first EdgeConv layer [1,64,N]
+        f = feats.cpu().numpy()
+        got = knn(feats, k, k)[0].cpu().numpy()
+        score = graph.knn_scores(f[0])[rows]
+        xx = (f[0].astype(np.float64) ** 2).sum(0)
+        scale = 2.0 * xx[rows]                                  # a row's neighbours have its own norm to within the distance
+    ref = np.argsort(-score, axis=1, kind="stable")[:, :k]
+    # (k = 64 on real features: most rows hold SOME near-tie among 64 neighbours, the exact-list rate is not the statement here)
+    check_idx(got[rows], ref, score, k, scale if metric == "feat" else None, min_same=0.8)

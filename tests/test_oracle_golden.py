@@ -315,3 +315,21 @@ def test_cylinder_scatter_of_the_reference(golden):
     assert max(d_perp) < 2e-2 and max(d_r) < 1e-3               # scatter of the reference around the limit
     assert np.median(d_perp) > 5e-4                             # ... which is why 1e-4 on (c, r) cannot be asked for
     assert max(gain) > 0.04
+
+
+def test_cylinder_exception_is_in_the_fixture(golden):
+    """a13: the reference's own cylinder centre / radius under a 1-ulp perturbation of the points (f_cyl.npz, generated by running
+    the reference) scatter by 1e-2 .. 1e-1; the noise-free limit of the same estimator moves by < 1e-5."""
+    g = golden("f_cyl")
+    off = g["offsets"]
+    ref_dc = np.linalg.norm(g["ulp_center"] - g["ref_center"], axis=1)
+    assert np.median(ref_dc) > 5e-3 and ref_dc.max() > 5e-2
+    assert np.abs(g["ulp_radius"] - g["ref_radius"]).max() > 1e-2
+    worst = 0.0
+    for i in range(0, off.shape[0] - 1, 4):
+        p, n = g["points"][off[i]:off[i + 1]], g["normals"][off[i]:off[i + 1]]
+        w = np.ones((p.shape[0], 1), np.float32) + np.finfo(np.float32).eps
+        _, c0, r0 = fit.fit_cylinder_exact(p, n, w)
+        _, c1, r1 = fit.fit_cylinder_exact(np.nextafter(p, np.float32(np.inf)).astype(np.float32), n, w)
+        worst = max(worst, float(np.abs(c1 - c0).max()), abs(float(r1) - float(r0)))
+    assert worst < 1e-5, worst

@@ -158,7 +158,8 @@ def roofline_block(timers, N, iterations, digits, counters=None):
         return None
     name = max(groups, key=lambda k_: sum(t for t, _ in groups[k_]))
     it = groups[name]
-    flops_per_cloud = 4.0 * N * N * 128 * iterations
+    D = int(it[0][1].get("D", 128))                               # 128, or 160 = the HPNet-widened embedding (140 columns padded)
+    flops_per_cloud = 4.0 * N * N * D * iterations
     avg_ms = float(np.mean([t for t, _ in it]))
     avg_clouds = float(np.mean([m["B"] for _, m in it]))
     ach = flops_per_cloud * avg_clouds / (avg_ms * 1e-3) / 1e12
@@ -167,11 +168,11 @@ def roofline_block(timers, N, iterations, digits, counters=None):
     mpp = mfma_per_product(digits)
     peak = F16_MFMA_PEAK_TFLOPS / mpp if split else FP32_MFMA_PEAK_TFLOPS
     blk = {"kernel": ("ms_iterate_d128_f16s_kernel<true, %s>" % ("true" if digits == 2 else "false")) if sparse else
-                     (("ms_iterate_d128_f16w_kernel<false, %s>" % ("true" if digits == 2 else "false")) if split
+                     (("ms_iterate_f16w_kernel<%d, %s, %s>" % (D // 32, "true" if D == 160 else "false", "true" if digits == 2 else "false")) if split
                       else "ms_iterate_d128_kernel"),
            "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
            "traffic": None, "traffic_source": None, "avg_launch_ms": round(avg_ms, 3), "launches_per_step": None,
-           "clouds_per_launch": round(avg_clouds, 2), "flops_per_launch": flops_per_cloud * avg_clouds,
+           "clouds_per_launch": round(avg_clouds, 2), "embedding_width": D, "flops_per_launch": flops_per_cloud * avg_clouds,
            "share_of_step": None,
            "note": (f"achieved = ALGORITHMIC fp32 flops of the reference's dense iteration (4 N^2 d per cloud and iteration) / "
                     f"launch time; the kernel evaluates every product as fp16 MFMAs on (h, l) splits ({mpp:g} MFMAs per product on "
@@ -404,6 +405,19 @@ def main():
                           "iteration kernel and nothing can be skipped -- the dense kernel's own roofline")
             line["unstructured"] = un
             del pipe_c, mc
+            # ---- the reference script's DEFAULT flow: HPNet spectral re-weighting on (generate_predictions_aug.py:58, :371-377)
+            pipe_h = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=args.iterations, hpnet=True)
+            torch.manual_seed(0)
+            hp = timed(pipe_h)
+            hp_sum, _ = leg_summary(hp, 2)
+            hp_sum["note"] = ("same step with the HPNet stage between the instance model and the clustering: farthest-50 normal "
+                              "affinity as a sparse operator, 12 leading eigenvectors by a batched LOBPCG that runs in HIP kernels on "
+                              "the device (Gram products, Jacobi Ritz solves, block updates: lobpcg.hip), entropy weights; the 140-d "
+                              "embedding (padded to 160) goes through the split-fp16 mean-shift kernel instantiated for five feature "
+                              "tiles (dense schedule; the block-sparse kernel exists for d = 128 only)")
+            hp_sum["x_headline_time_per_cloud"] = round(hp_sum["ms_per_step"] / head_sum["ms_per_step"], 3)
+            line["hpnet"] = hp_sum
+            del pipe_h
     if rank == 0:
         if world == 1 and args.k != 64 and not args.no_k64:
             # also report the reference's default neighbourhood size k = 64 (same clouds, same path)

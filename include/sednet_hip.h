@@ -66,17 +66,35 @@ int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx
  * Replaces knn_idx (square_distance(...).topk(k), largest)            src/smooth_normal_matrix.py:33-40 */
 int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
                           int* overflow, sed_stream_t stream);
-/* Y [B,N,ncol] = M X, M = B matrices in CSR sharing the entry capacity nnz_stride (rowptr [B,N+1], col / val
- * [B,nnz_stride]); ncol in {4,8,12,16,24,36}. The sparse part of the HPNet affinity operator (one wave per row,
- * deterministic).                                                       src/smooth_normal_matrix.py:42-92, :198 */
+/* Y [B,N,ldy] (first ncol columns) = M X, M = B matrices in CSR sharing the entry capacity nnz_stride (rowptr [B,N+1], col /
+ * val [B,nnz_stride]); X [B,N,ldx]; ncol in {4,8,12,16,24,36}. The sparse part of the HPNet affinity operator (one wave per
+ * row, deterministic).                                                  src/smooth_normal_matrix.py:42-92, :198 */
 int sed_csr_spmm_f32(int B, int N, int ncol, size_t nnz_stride, const int* rowptr, const int* col, const float* val,
-                     const float* X, float* Y, sed_stream_t stream);
+                     const float* X, int ldx, float* Y, int ldy, sed_stream_t stream);
+/* ---- batched LOBPCG on the device (the arithmetic inside torch.lobpcg(A, k = 12, niter = 10), src/smooth_normal_matrix.py:198;
+ * lobpcg.hip). The search block lives in two caller-owned buffers S, AS [B,N,ld] with columns [X (k) | R (k) | P (k)]. Nothing is
+ * copied to the host between the calls of an iteration.
+ * out [B,ma,mb] fp64 = A^T Bm for tall-skinny A [B,N,lda], Bm [B,N,ldb] (ma, mb <= 36; fp64 accumulation, fixed-order) */
+size_t sed_tsgemm_tn_workspace_bytes(int B, int N, int ma, int mb);
+int sed_tsgemm_tn_f64(int B, int N, int ma, int mb, const float* A, int lda, const float* Bm, int ldb, double* out, void* ws,
+                      size_t ws_bytes, sed_stream_t stream);
+/* Rayleigh-Ritz: G = S^T S, H = S^T A S [B,m,m] fp64 (m in {12, 24, 36}) -> C [B,m,k] fp32 with C^T G C = I spanning the k largest
+ * Ritz pairs (two cyclic Jacobi eigen-decompositions in fp64 per cloud, numerically dependent directions cut off), theta [B,k] */
+int sed_ritz_f64(int B, int m, int k, const double* G, const double* H, float* C, float* theta, sed_stream_t stream);
+/* R = AX - X lam;  R -= X (X^T R);  R /= ||R|| per column   (lam [B,k]) */
+size_t sed_lobpcg_workspace_bytes(int B, int N, int k);
+int sed_lobpcg_residual_f32(int B, int N, int k, float* S, const float* AS, int ld, const float* lam, void* ws, size_t ws_bytes,
+                            sed_stream_t stream);
+/* X <- S C, AX <- AS C, P <- S Cp, AP <- AS Cp in place (m = k, 2 k or 3 k columns in use; Cp = C with its first k rows zeroed) */
+int sed_lobpcg_update_f32(int B, int N, int m, int k, float* S, float* AS, int ld, const float* C, sed_stream_t stream);
+/* Y [B,N,ldy] (first k columns) += alpha d t^T, d [B,N], t [B,k] fp64: the rank-one background of the affinity operator */
+int sed_rank1_add_f32(int B, int N, int k, float* Y, int ldy, const float* d, const double* t, float alpha, sed_stream_t stream);
 
 /* ---- mean-shift clustering --------------------------------------------------------------------------- */
 /* bw[b] = max(mean_i sqrt(max(kth[b,i], 1e-6)), min_bw)      src/mean_shift.py:135-137, :34 */
 int sed_ms_bandwidth_finalize_f32(int B, int N, float min_bw, const float* kth, float* bw, sed_stream_t stream);
 /* K-th smallest (1-based, self included) of 2 - 2 x_i.x_j per row WITHOUT the N x N matrix (two MFMA sweeps + short
- * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128}, K <= sed_ms_kth_fused_max_k(N)
+ * candidate lists; bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32). d in {32,64,96,128,160}, K <= sed_ms_kth_fused_max_k(N)
  * (160; 224 on clouds of >= 4096 points, where the first sweep samples every other key tile).
  * overflow [B] (device ints): overflow[b] becomes 1 if a candidate list of cloud b overflowed: kth[b] is then invalid, use
  * the materialised path for that cloud.

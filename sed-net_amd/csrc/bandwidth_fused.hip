@@ -328,7 +328,7 @@ extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, 
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
     if (sampling != 0 && sampling != 2 && sampling != 4) return SED_EINVAL;
     const bool quarter = sampling != 2;
-    if (d % 32 != 0 || d < 32 || d > 128 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
+    if (d % 32 != 0 || d < 32 || d > 160 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
     hipError_t e = hipMemsetAsync(overflow, 0, (size_t)B * sizeof(int), stream);
@@ -337,7 +337,8 @@ extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, 
         case 1: launch_kth<1>(B, X, w, N, K, overflow, quarter, stream); break;
         case 2: launch_kth<2>(B, X, w, N, K, overflow, quarter, stream); break;
         case 3: launch_kth<3>(B, X, w, N, K, overflow, quarter, stream); break;
-        default: launch_kth<4>(B, X, w, N, K, overflow, quarter, stream); break;
+        case 4: launch_kth<4>(B, X, w, N, K, overflow, quarter, stream); break;
+        default: launch_kth<5>(B, X, w, N, K, overflow, quarter, stream); break;     // d = 160 (HPNet-widened embedding): exact fp32 products
     }
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;

@@ -40,7 +40,8 @@ __device__ __forceinline__ float exp_compensated(float a) {
 template <int NT>
 __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restrict__ X,
                                                             float* __restrict__ newX,
-                                                            const float* __restrict__ bw, int N, int iters) {
+                                                            const float* __restrict__ bw, int N, int iters,
+                                                            const int* __restrict__ only = nullptr) {
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;   // float4 per row
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void ms_iterate_kernel(const float* __restr
     const int li = lane & 31, hi = lane >> 5;
     int bxi;
     const int cloud = sed_xcd_cloud_block(&bxi);          // whole clouds per XCD (common.h)
+    if (only && !only[cloud]) return;                     // fallback pass behind the split-fp16 kernel: flagged clouds only
     const float* Xc = X + (size_t)cloud * N * D;
     const int qrow = bxi * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
@@ -804,9 +806,9 @@ enum { MS_BATCHED = 1, MS_SPLITK = 2, MS_CHUNKED = 3, MS_F16 = 4, MS_F16_CHUNKED
 int ms_plan(int B, int N, int d, bool have_ws, bool have_f16, int forced) {
     const long W = (long)B * ((N + 127) / 128), W4 = (long)B * ((N + 31) / 32);
     const int S = ms_chunks(N);
-    if (forced == MS_F16) return (d == 128 && have_f16) ? MS_F16 : MS_BATCHED;
-    if (forced == MS_F16_CHUNKED) return (d == 128 && have_f16 && ms_f16_chunks(N)) ? MS_F16_CHUNKED : MS_BATCHED;
-    if (!forced && d == 128 && have_f16) {
+    if (forced == MS_F16) return ((d == 128 || d == 160) && have_f16) ? MS_F16 : MS_BATCHED;
+    if (forced == MS_F16_CHUNKED) return ((d == 128 || d == 160) && have_f16 && ms_f16_chunks(N)) ? MS_F16_CHUNKED : MS_BATCHED;
+    if (!forced && (d == 128 || d == 160) && have_f16) {     // d = 160: the HPNet-widened embedding (140 columns, zero padded)
         // few clouds: the 256-row workgroups of the split-fp16 kernel leave CUs idle; its key-chunked form fills them
         // (cost in rounds of 256 workgroups x stages per workgroup, +10 % for the partials)
         const int Sf = ms_f16_chunks(N);
@@ -827,13 +829,13 @@ int ms_plan(int B, int N, int d, bool have_ws, bool have_f16, int forced) {
 }  // namespace
 
 // ms_iterate_f16.hip
-size_t ms_f16_chunked_workspace_bytes(int B, int N);
-int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+size_t ms_f16_chunked_workspace_bytes(int B, int N, int d);
+int ms_f16_chunked_launch(int B, int N, int d, int S, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
-                                                          int, int*, hipStream_t),
+                                                          int, int, int*, hipStream_t),
                           int digits, int wq, hipStream_t stream);
-size_t ms_f16_workspace_bytes(int B, int N);
-int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+size_t ms_f16_workspace_bytes(int B, int N, int d);
+int ms_f16_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
                   int** flags_out, int digits, int wq, hipStream_t stream);
 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
@@ -842,8 +844,8 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
                          float margin, unsigned long long* stats, int digits, hipStream_t stream);
 
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
-                             int N, int* lowq, hipStream_t stream) {
-    ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, 128, N, lowq);
+                             int d, int N, int* lowq, hipStream_t stream) {
+    ms_combine_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(partO, partS, Qin, Qout, rows, S, d, N, lowq);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -869,8 +871,9 @@ extern "C" int sed_ms_iterate_plan(int B, int N, int d, const sed_ms_options* op
 extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options* opt) {
     if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0 || !opt_valid(opt)) return 0;
     const int plan = ms_plan(B, N, d, true, true, opt_schedule(opt));
-    if (plan == MS_F16) return ms_f16_workspace_bytes(B, N);
-    if (plan == MS_F16_CHUNKED) return ms_f16_chunked_workspace_bytes(B, N);
+    if (plan == MS_F16 && d != 160) return ms_f16_workspace_bytes(B, N, d);
+    if (plan == MS_F16) return ms_f16_chunked_workspace_bytes(B, N, d);       // d = 160 runs whole sweeps through the chunked form
+    if (plan == MS_F16_CHUNKED) return ms_f16_chunked_workspace_bytes(B, N, d);
     if (plan != MS_CHUNKED) return 0;
     return (size_t)B * N * ms_chunks(N) * (d + 1) * sizeof(float);
 }
@@ -893,14 +896,16 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     dim3 grid((N + 127) / 128, B), block(256);
     const int S = ms_chunks(N);
     const size_t need = (size_t)B * N * S * (d + 1) * sizeof(float);
-    const bool have_f16 = iters > 0 && workspace && d == 128 && workspace_bytes >= ms_f16_workspace_bytes(B, N);
+    const bool have_f16 = iters > 0 && workspace && (d == 128 || d == 160) &&
+                          workspace_bytes >= (d == 160 ? ms_f16_chunked_workspace_bytes(B, N, d) : ms_f16_workspace_bytes(B, N, d));
     int plan = ms_plan(B, N, d, iters > 0 && workspace && workspace_bytes >= need, have_f16, forced);
-    if (plan == MS_F16_CHUNKED && workspace_bytes < ms_f16_chunked_workspace_bytes(B, N)) plan = MS_F16;
+    if (plan == MS_F16_CHUNKED && workspace_bytes < ms_f16_chunked_workspace_bytes(B, N, d)) plan = MS_F16;
     if (plan == MS_F16 || plan == MS_F16_CHUNKED) {
         int* flags = nullptr;
-        const int rc = plan == MS_F16 ? ms_f16_launch(B, N, iters, bw, X, newX, workspace, &flags, digits, wq, stream)
-                                      : ms_f16_chunked_launch(B, N, iters, bw, X, newX, workspace, &flags,
-                                                              ms_combine_launch, digits, wq, stream);
+        const int rc = (plan == MS_F16 && d != 160)
+                           ? ms_f16_launch(B, N, d, iters, bw, X, newX, workspace, &flags, digits, wq, stream)
+                           : ms_f16_chunked_launch(B, N, d, plan == MS_F16 ? 1 : ms_f16_chunks(N), iters, bw, X, newX, workspace,
+                                                   &flags, ms_combine_launch, digits, wq, stream);
         if (rc != SED_OK) return rc;
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud
@@ -912,7 +917,8 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
             if (e != hipSuccess) return (int)e;
             attr_fb = true;
         }
-        ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
+        if (d == 160) ms_iterate_kernel<5><<<grid, block, 0, stream>>>(X, newX, bw, N, iters, flags);
+        else ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
         SED_LAUNCH_CHECK();
         return SED_OK;
     }

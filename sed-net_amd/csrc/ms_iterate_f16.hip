@@ -569,8 +569,57 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16r_kernel(const floa
 #ifndef F16W_RING_DISTANCE
 #define F16W_RING_DISTANCE 1
 #endif
-template <bool CHUNKED = false, bool PL = true>
-__global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const float* __restrict__ X,
+// NT = feature tiles of 32: 4 (d = 128, the SED-Net embedding) or 5 (d = 160: the 140 columns of the HPNet-widened embedding,
+// generate_predictions_aug.py:371-377, zero padded). Row-major stage images of 32 keys x NT * 32 features, rows padded by 16 B.
+template <int NT>
+struct StageLayoutD {
+    static constexpr int D = 32 * NT, XROW = 2 * D + 16, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, STAGE = 2 * XPLANE;
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");             // 17408 B (NT = 4), 21504 B (NT = 5)
+};
+static_assert(StageLayoutD<4>::STAGE == StageLayoutN::STAGE && StageLayoutD<4>::XROW == StageLayoutN::XROW, "same images at d = 128");
+
+template <int NT>
+__global__ __launch_bounds__(256) void ms_split_d_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                         uint8_t* __restrict__ blob, int* __restrict__ flags, int N, int nst) {
+    using L = StageLayoutD<NT>;
+    constexpr int D = L::D, Q4 = D / 4;                       // float4s per row
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * D;
+    uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
+    __shared__ float n2row[32];
+    if (tid < 32) n2row[tid] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < 32 * Q4; e += 256) {
+        const int kk = e / Q4, d0 = (e - kk * Q4) * 4;
+        const int key = stage * 32 + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + d0);
+        atomicAdd(&n2row[kk], v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);   // only compared with a threshold: order-free
+        typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = v[u] * SCALE_X;
+            const h16 h = (h16)sc;
+            hh[u] = h;
+            ll[u] = (h16)(sc - (float)h);
+        }
+        *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
+        *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+    }
+    if (tid < 64) {
+        const int kk = tid & 31, pl = tid >> 5;
+        *(uint4*)(dst + pl * L::XPLANE + kk * L::XROW + 2 * D) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float b = bw[cloud];
+        if (!((n2row[tid] - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
+    }
+}
+
+template <int NT = 4, bool CHUNKED = false, bool PL = true>
+__global__ __launch_bounds__(256, 1) void ms_iterate_f16w_kernel(const float* __restrict__ X,
                                                                       const uint8_t* __restrict__ blob,
                                                                       float* __restrict__ newX,
                                                                       const float* __restrict__ bw,
@@ -579,7 +628,8 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                                                                       float* __restrict__ partO = nullptr,
                                                                       float* __restrict__ partS = nullptr,
                                                                       int* __restrict__ lowq = nullptr) {
-    using L = StageLayoutN;
+    using L = StageLayoutD<NT>;
+    constexpr int D = L::D, KS = 2 * NT, NSTEP = 4 * NT;  // k-steps of the first product, operand steps of a block
     constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int NBUF = 3;
     constexpr int RD = F16W_RING_DISTANCE;             // one step ahead = 6 / 4 MFMAs (192 / 128 matrix cycles) per operand pair
@@ -592,7 +642,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
     const int cloud = sed_xcd_cloud_block(&bx);
     if (flags[cloud]) return;
     if (PL && lowq != nullptr && !lowq[cloud]) return;
-    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * 128;
+    const float* Xc = (CHUNKED ? Qin : X) + (size_t)cloud * N * D;
     const int nst = (N + 31) >> 5;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
     int qrow[2], qrow_c[2];
@@ -610,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
     const float K0 = LOG2_SCALE_P - inv_b2_l2e;
     const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
 
-    h16x8 qh[2][8], ql[2][8];
+    h16x8 qh[2][KS], ql[2][KS];
     auto split_q = [&](int g, int ks, const float* v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -622,32 +672,36 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             float v[8];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c[g] * 128 + 16 * ks + 8 * hi + 4 * q);
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c[g] * D + 16 * ks + 8 * hi + 4 * q);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[4 * q + u] = t[u] * SCALE_X;
             }
             split_q(g, ks, v);
         }
 
-    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces 4 w .. 4 w + 3 (immediate offsets), wave 0 also piece 16
-    static_assert(NPIECE == 17, "piece distribution below is written for 17 pieces");
+    // DMA pieces (1 KiB each) of a stage image: wave w moves pieces PW w .. PW w + PW - 1 (immediate offsets), wave 0 also the last
+    constexpr int PW = NPIECE / 4;
+    static_assert(NPIECE == 4 * PW + 1 && (PW == 4 || PW == 5), "piece distribution below is written for 17 / 21 pieces");
     const unsigned lane16 = lane * 16;
     auto stage_dma = [&](int st, int buf) {
         const uint8_t* src = blob_c + (size_t)st * STAGE;
         uint8_t* dst = lds + buf * STAGE;
-        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
-        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
+        const auto g = (const __attribute__((address_space(1))) void*)(src + wave * (PW * 1024) + lane16);
+        const auto l = (__attribute__((address_space(3))) void*)(dst + wave * (PW * 1024));
         __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
         __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
         __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        if constexpr (PW == 5)        // (own base pointers: the instruction's immediate offset is 13-bit signed, 4096 does not fit)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * (PW * 1024) + 4096 + lane16),
+                                             (__attribute__((address_space(3))) void*)(dst + wave * (PW * 1024) + 4096), 16, 0, 0);
         if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * 1024 + lane16),
-                                             (__attribute__((address_space(3))) void*)(dst + 16 * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * PW * 1024 + lane16),
+                                             (__attribute__((address_space(3))) void*)(dst + 4 * PW * 1024), 16, 0, 0);
     };
     auto advance = [&](int& st, bool& fwd) {
         if (fwd) {
@@ -692,11 +746,11 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         return __builtin_bit_cast(h16x8, both);
     };
     auto ring_load = [&](int t, const uint8_t* base) {
-        if (t < 8) {
+        if (t < KS) {
             fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
             fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
         } else {
-            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
             fa[t & 3] = tr8(base + OFF_XH, c, j);
             fb[t & 3] = tr8(base + OFF_XL, c, j);
         }
@@ -708,7 +762,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_cur[g][r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < KS; ++t) {
             const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
             const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
 #pragma unroll
@@ -720,11 +774,11 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         }
     };
 
-    f32x16 o[2][4];
+    f32x16 o[2][NT];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
     float rsum[2] = {0.f, 0.f};
@@ -776,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
         // ---- phase 1: first product of block n + 1 (both query groups) with the weights of block n between its MFMAs
         auto phase1 = [&](auto tail_c) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < KS; ++t) {
                 if (t == 0) {
                     f32x16 z;
 #pragma unroll
@@ -787,13 +841,13 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                     s_next[0] = mfma16(fb[t & 3], qh[0][t], s_next[0]);
                     s_next[1] = mfma16(fb[t & 3], qh[1][t], s_next[1]);
                 }
-                weights2(0, t, tail_c);
+                if (t < 8) weights2(0, t, tail_c);              // 16 accumulator rows = 8 pairs
                 s_next[0] = mfma16(fa[t & 3], ql[0][t], s_next[0]);
                 s_next[1] = mfma16(fa[t & 3], ql[1][t], s_next[1]);
-                weights2(1, t, tail_c);
+                if (t < 8) weights2(1, t, tail_c);
                 s_next[0] = mfma16(fa[t & 3], qh[0][t], s_next[0]);
                 s_next[1] = mfma16(fa[t & 3], qh[1][t], s_next[1]);
-                if (t + RD < 8) ring_load(t + RD, nbase);
+                if (t + RD < KS) ring_load(t + RD, nbase);
                 else ring_load(t + RD, base);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -807,21 +861,23 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s_next[g][r] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 8; ++t) {                          // (16 accumulator rows = 8 pairs, whatever the feature width)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     if (tail) weights2(g, t, std::true_type{});
                     else weights2(g, t, std::false_type{});
                 }
-                if (t + RD >= 8) ring_load(t + RD, base);
             }
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+                if (t + RD >= KS) ring_load(t + RD, base);
             __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- phase 2: second product of block n, both query groups per operand read
 #pragma unroll
-        for (int t = 8; t < 16; ++t) {
-            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+        for (int t = KS; t < NSTEP; ++t) {
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
 #pragma unroll
             for (int g = 0; g < 2; ++g) o[g][c] = mfma16(fb[t & 3], __builtin_bit_cast(h16x8, phv[g][j]), o[g][c]);
             if (PL) {
@@ -830,10 +886,10 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
             }
 #pragma unroll
             for (int g = 0; g < 2; ++g) o[g][c] = mfma16(fa[t & 3], __builtin_bit_cast(h16x8, phv[g][j]), o[g][c]);
-            if (t + RD < 16) ring_load(t + RD, base);
-            else if (n + 2 < total) ring_load(t + RD - 16, n2base);
+            if (t + RD < NSTEP) ring_load(t + RD, base);
+            else if (n + 2 < total) ring_load(t + RD - NSTEP, n2base);
             __builtin_amdgcn_sched_barrier(0);
-            if (t == 15 - RD) {
+            if (t == NSTEP - 1 - RD) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (n + 3 < total) stage_dma(st_dma, buf);
@@ -856,7 +912,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(ql[g][t]));
+            for (int t = 0; t < KS; ++t) asm volatile("" : "+a"(ql[g][t]));
 #endif
         for (int i = 0; i + 1 < len; ++i) block(std::true_type{});
         if (len > 0) block(std::false_type{});
@@ -874,7 +930,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
             // spill; the additions into n2 keep the order of the 8-wave kernel: tile by tile, register by register)
             float n2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NT; ++c) {
                 float qacc[16];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -907,9 +963,9 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
                 const int qr = bx * 256 + wave * 64 + g * 32 + (l & 31), hl = l >> 5;
                 if (qr < N) {
-                    float* out = newX + ((size_t)cloud * N + qr) * 128;
+                    float* out = newX + ((size_t)cloud * N + qr) * D;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < NT; ++c)
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
                             f32x4 v = {o[g][c][4 * q4] / nrm, o[g][c][4 * q4 + 1] / nrm, o[g][c][4 * q4 + 2] / nrm,
@@ -919,7 +975,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         float v[8];
@@ -934,7 +990,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
                         split_q(g, 2 * c + j, v);
                     }
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
                 rsum[g] = 0.f;
@@ -950,9 +1006,9 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_d128_f16w_kernel(const floa
             const float rs = rsum[g] + xor32(rsum[g]);
             if (qrow[g] < N) {
                 const size_t slot = ((size_t)cloud * N + qrow[g]) * nchunk + chunk;
-                float* out = partO + slot * 128;
+                float* out = partO + slot * D;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         constexpr float U = 1.0f / 33554432.0f;          // 2^-25
@@ -1388,11 +1444,30 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
 // calls (the function-local `attr` flags only remember that a kernel's dynamic-LDS limit has been raised once).
 
 static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
-static size_t f16_blob_bytes_n(int B, int N) { return (size_t)B * ((N + 31) / 32) * StageLayoutN::STAGE; }       // row-major images
+static size_t f16_blob_bytes_n(int B, int N, int d) {                                      // row-major images
+    return (size_t)B * ((N + 31) / 32) * (d == 160 ? StageLayoutD<5>::STAGE : StageLayoutD<4>::STAGE);
+}
 static size_t f16_blob_bytes_4(int B, int N) { return (size_t)B * ((N + 31) / 32) * StageLayout<32>::STAGE; }    // four-plane images
 
 // stage images | "rows not unit" flags | "weighted means cancel" flags (both per cloud, 256-byte blocks)
-size_t ms_f16_workspace_bytes(int B, int N) { return f16_blob_bytes_n(B, N) + 2 * f16_flag_bytes(B); }
+size_t ms_f16_workspace_bytes(int B, int N, int d) { return f16_blob_bytes_n(B, N, d) + 2 * f16_flag_bytes(B); }
+
+template <int NT>
+static int f16w_attr() {
+    static bool attr = false;
+    if (attr) return SED_OK;
+    constexpr int sm = 3 * StageLayoutD<NT>::STAGE;
+    hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+    return SED_OK;
+}
 
 static int f16r_attr() {
     static bool attr = false;
@@ -1407,42 +1482,51 @@ static int f16r_attr() {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16r_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
     attr = true;
     return SED_OK;
 }
 
+// the 64-queries-per-wave kernel (any of its four forms) for feature width 32 NT
+template <int NT>
+static void f16w_run(bool chunked, bool pl, dim3 grid, const float* X, const uint8_t* blob, float* newX, const float* bw,
+                     const int* flags, int N, int iters, const float* Q, float* partO, float* partS, int* lowq, hipStream_t stream) {
+    constexpr int sm = 3 * StageLayoutD<NT>::STAGE;
+    if (chunked && pl) ms_iterate_f16w_kernel<NT, true, true><<<grid, 256, sm, stream>>>(X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq);
+    else if (chunked) ms_iterate_f16w_kernel<NT, true, false><<<grid, 256, sm, stream>>>(X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq);
+    else if (pl) ms_iterate_f16w_kernel<NT, false, true><<<grid, 256, sm, stream>>>(X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq);
+    else ms_iterate_f16w_kernel<NT, false, false><<<grid, 256, sm, stream>>>(X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq);
+}
+static void f16w_any(int d, bool chunked, bool pl, dim3 grid, const float* X, const uint8_t* blob, float* newX, const float* bw,
+                     const int* flags, int N, int iters, const float* Q, float* partO, float* partS, int* lowq, hipStream_t stream) {
+    if (d == 160) f16w_run<5>(chunked, pl, grid, X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq, stream);
+    else f16w_run<4>(chunked, pl, grid, X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq, stream);
+}
+
 // one launch, all iterations; flags live behind the stage images; *flags_out = the per-cloud "rows not unit" flags the exact
-// fp32 kernel reads
-int ms_f16_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace, int** flags_out,
+// fp32 kernel reads. d = 128, or 160 (the HPNet-widened embedding; 64-queries-per-wave kernel only)
+int ms_f16_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace, int** flags_out,
                   int digits, int wq, hipStream_t stream) {
     using L = StageLayoutN;
     uint8_t* blob = (uint8_t*)workspace;
-    int* flags = (int*)(blob + f16_blob_bytes_n(B, N));
+    int* flags = (int*)(blob + f16_blob_bytes_n(B, N, d));
     int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
     if (e != hipSuccess) return (int)e;
-    const int rc = f16r_attr();
+    int rc = f16r_attr();
+    if (rc == SED_OK) rc = f16w_attr<4>();
+    if (rc == SED_OK) rc = f16w_attr<5>();
     if (rc != SED_OK) return rc;
     const int nst = (N + 31) / 32;
     const dim3 grid((N + 255) / 256, B);
-    ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
-    if (wq == 64) {              // 64 queries per wave: 4-wave workgroups, one wave per SIMD (same bits)
+    if (d == 160) ms_split_d_kernel<5><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    else ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    if (wq == 64 || d == 160) {  // 64 queries per wave: 4-wave workgroups, one wave per SIMD (same bits as the 8-wave kernel at d = 128)
         if (digits == 2) {
-            ms_iterate_d128_f16w_kernel<false, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters);
+            f16w_any(d, false, true, grid, X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, nullptr, stream);
         } else {
-            ms_iterate_d128_f16w_kernel<false, false><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters,
-                                                                                           nullptr, nullptr, nullptr, lowq);
-            ms_iterate_d128_f16w_kernel<false, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters,
-                                                                                          nullptr, nullptr, nullptr, lowq);
+            f16w_any(d, false, false, grid, X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq, stream);
+            f16w_any(d, false, true, grid, X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq, stream);
         }
     } else if (digits == 2) {
         ms_iterate_d128_f16r_kernel<false, true><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, iters);
@@ -1466,40 +1550,43 @@ int ms_f16_chunks(int N) {
     return S < 2 ? 0 : S;
 }
 
-static size_t f16_chunked_base_bytes(int B, int N) { return f16_blob_bytes_n(B, N) + 2 * f16_flag_bytes(B); }
+static size_t f16_chunked_base_bytes(int B, int N, int d) { return f16_blob_bytes_n(B, N, d) + 2 * f16_flag_bytes(B); }
 
-size_t ms_f16_chunked_workspace_bytes(int B, int N) {
-    return f16_chunked_base_bytes(B, N) + (size_t)B * N * ms_f16_chunks(N) * 129 * sizeof(float) + 256;
+size_t ms_f16_chunked_workspace_bytes(int B, int N, int d) {
+    const int S = ms_f16_chunks(N) > 1 ? ms_f16_chunks(N) : 1;
+    return f16_chunked_base_bytes(B, N, d) + (size_t)B * N * S * (d + 1) * sizeof(float) + 256;
 }
 
-// one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher
-int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+// one launch pair per iteration; `combine` = ms_iterate.hip's ms_combine_kernel launcher. S = key chunks per query block
+// (ms_f16_chunks(N) when few clouds would leave CUs idle; 1 = whole sweeps, the form the d = 160 kernel always takes: its
+// one-launch instantiation does not fit the register file)
+int ms_f16_chunked_launch(int B, int N, int d, int S, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
-                                                          int, int*, hipStream_t),
+                                                          int, int, int*, hipStream_t),
                           int digits, int wq, hipStream_t stream) {
     using L = StageLayoutN;
-    const int nst = (N + 31) / 32, S = ms_f16_chunks(N);
+    const int nst = (N + 31) / 32;
     uint8_t* blob = (uint8_t*)workspace;
-    int* flags = (int*)(blob + f16_blob_bytes_n(B, N));
-    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + f16_chunked_base_bytes(B, N)) + 255) & ~(uintptr_t)255);
-    float* partS = partO + (size_t)B * N * S * 128;
+    int* flags = (int*)(blob + f16_blob_bytes_n(B, N, d));
+    float* partO = (float*)(((uintptr_t)((uint8_t*)workspace + f16_chunked_base_bytes(B, N, d)) + 255) & ~(uintptr_t)255);
+    float* partS = partO + (size_t)B * N * S * d;
     int* lowq = (int*)((uint8_t*)flags + f16_flag_bytes(B));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, 2 * f16_flag_bytes(B), stream);
     if (e != hipSuccess) return (int)e;
-    const int rca = f16r_attr();
+    int rca = f16r_attr();
+    if (rca == SED_OK) rca = f16w_attr<4>();
+    if (rca == SED_OK) rca = f16w_attr<5>();
     if (rca != SED_OK) return rca;
     const bool heads = digits != 2;
+    const bool wide = wq == 64 || d == 160;
     const dim3 grid((N + 255) / 256, B, S);
-    ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    if (d == 160) ms_split_d_kernel<5><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    else ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
     for (int it = 0; it < iters; ++it) {
         const float* Q = it == 0 ? X : newX;
-        if (wq == 64 && heads)
-            ms_iterate_d128_f16w_kernel<true, false><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
-                                                                                         partS);
-        else if (wq == 64)
-            ms_iterate_d128_f16w_kernel<true, true><<<grid, 256, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
-                                                                                        partS);
+        if (wide)
+            f16w_any(d, true, !heads, grid, X, blob, newX, bw, flags, N, 1, Q, partO, partS, nullptr, stream);
         else if (heads)
             ms_iterate_d128_f16r_kernel<true, false><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
                                                                                          partS);
@@ -1507,13 +1594,13 @@ int ms_f16_chunked_launch(int B, int N, int iters, const float* bw, const float*
             ms_iterate_d128_f16r_kernel<true, true><<<grid, 512, 3 * L::STAGE, stream>>>(X, blob, newX, bw, flags, N, 1, Q, partO,
                                                                                         partS);
         // the combine kernel sees the norm of every weighted mean: with heads-only weights it flags clouds whose means cancel
-        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, N, heads ? lowq : nullptr, stream);
+        const int rc = combine(partO, partS, Q, newX, (size_t)B * N, S, d, N, heads ? lowq : nullptr, stream);
         if (rc != SED_OK) return rc;
     }
     if (heads && iters > 0) {                         // flagged clouds again, (h, l) weights, all iterations in one launch
-        if (wq == 64)
-            ms_iterate_d128_f16w_kernel<false, true><<<dim3((N + 255) / 256, B), 256, 3 * L::STAGE, stream>>>(
-                X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);
+        if (wide)
+            f16w_any(d, false, true, dim3((N + 255) / 256, B), X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq,
+                     stream);
         else
             ms_iterate_d128_f16r_kernel<false, true><<<dim3((N + 255) / 256, B), 512, 3 * L::STAGE, stream>>>(
                 X, blob, newX, bw, flags, N, iters, nullptr, nullptr, nullptr, lowq);

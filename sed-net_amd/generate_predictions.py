@@ -2,15 +2,16 @@
 """Batched MI355X counterpart of /root/reference/generate_predictions_aug.py (call sequence :142-441).
 
     python generate_predictions.py <config.yml> NoSave|Save no_multi_vote|multi_vote no_fold5drop|fold5drop \\
-           [--input 'clouds/*.npz' | --synthetic 16] [--batch 64] [--out predictions] [--hpnet]
+           [--input 'clouds/*.npz' | --synthetic 16] [--batch 64] [--out predictions] [--no-hpnet]
 
 Same positional argv contract as the reference (:8, :76, :79, :85), same two models (type model `model`, instance model
 `model_inst`, :142-170) with "module."-tolerant checkpoint loading (:191-198), same test-time augmentation of the
 type model (:238-362), row-normalised embedding, guard_mean_shift(quantile 0.015, 50 iterations, x1.2 while > 49
 clusters), and the same output files `{id}_inst.txt`, `{id}_type.txt` (%d) and `{id}_edge.txt` (softmax, %0.4f, ';')
 (:424-437). What differs by design: clouds are processed B at a time on the device, the dataset loader (HDF5,
-out of scope) is replaced by .npz files or synthetic clouds, and HPNet spectral re-weighting (on in the reference,
-:58) is opt-in (`--hpnet`) because its lobpcg initialisation is random (statistical parity only).
+out of scope) is replaced by .npz files or synthetic clouds. HPNet spectral re-weighting is ON by default like in the
+reference (:58, :371-377; its lobpcg start is random there as here, so instance labels agree with a reference run statistically;
+`--no-hpnet` switches it off for exact label parity with a reference run that has use_hpnet = False).
 """
 import argparse
 import glob
@@ -117,10 +118,11 @@ def main(argv=None):
                     help="clouds per pipeline call (the reference processes one at a time; 64 = the benchmarked configuration, "
                          "~15 GB of device memory at 10 000 points; results do not depend on it beyond summation order)")
     ap.add_argument("--out", default="./predictions/results")
-    ap.add_argument("--hpnet", action="store_true",
-                    help="HPNet spectral re-weighting of the embedding (on by default in the reference, :58; off here because "
-                         "its lobpcg start is random: with identical argv the instance labels differ from the reference's "
-                         "unless this flag is given)")
+    ap.add_argument("--no-hpnet", dest="hpnet", action="store_false",
+                    help="switch the HPNet spectral re-weighting of the embedding off (default: on, like the reference's "
+                         "use_hpnet = True at :58; its lobpcg start is random, so labels match a reference run statistically)")
+    ap.add_argument("--hpnet", dest="hpnet", action="store_true", help="(default) HPNet spectral re-weighting on")
+    ap.set_defaults(hpnet=True)
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="closed-form synthetic weights instead of the checkpoints named by the config (tests, benchmarks)")
     ap.add_argument("--ms-weight-digits", type=int, choices=[1, 2], default=2,

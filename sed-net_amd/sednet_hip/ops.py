@@ -111,12 +111,54 @@ def knn_farthest(P, k):
     return idx
 
 
-def csr_spmm(rowptr, col, val, X):
-    """Y [B,N,c] = M X for B CSR matrices (rowptr [B,N+1] i32, col / val [B,nnz]) -- the HPNet affinity operator."""
+def csr_spmm(rowptr, col, val, X, out=None):
+    """Y [B,N,c] = M X for B CSR matrices (rowptr [B,N+1] i32, col / val [B,nnz]) -- the HPNet affinity operator. X / out may
+    be column slices [B,N,c] of wider row-major buffers (row stride = ld)."""
     B, N, c = X.shape
-    Y = torch.empty_like(X)
-    check(lib.sed_csr_spmm_f32(B, N, c, col.shape[1], ptr(rowptr), ptr(col), ptr(val), ptr(X), ptr(Y), stream()), "csr_spmm")
+    Y = torch.empty((B, N, c), dtype=torch.float32, device=X.device) if out is None else out
+    check(lib.sed_csr_spmm_f32(B, N, c, col.shape[1], ptr(rowptr), ptr(col), ptr(val), _vptr(X), X.stride(1), _vptr(Y),
+                               Y.stride(1), stream()), "csr_spmm")
     return Y
+
+
+def tsgemm_tn(A, Bm):
+    """[B,ma,mb] fp64 = A^T Bm for tall-skinny column slices A [B,N,ma], Bm [B,N,mb] of row-major buffers (lobpcg.hip)."""
+    B, N, ma = A.shape
+    mb = Bm.shape[2]
+    out = torch.empty((B, ma, mb), dtype=torch.float64, device=A.device)
+    nws = lib.sed_tsgemm_tn_workspace_bytes(B, N, ma, mb)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=A.device)
+    check(lib.sed_tsgemm_tn_f64(B, N, ma, mb, _vptr(A), A.stride(1), _vptr(Bm), Bm.stride(1), ptr(out), ptr(ws), nws, stream()),
+          "tsgemm_tn")
+    return out
+
+
+def ritz(G, H, k):
+    """largest-k Ritz pairs of H c = theta G c, G / H [B,m,m] fp64 on the device -> (C [B,m,k] fp32, theta [B,k] fp32)"""
+    B, m, _ = G.shape
+    C = torch.empty((B, m, k), dtype=torch.float32, device=G.device)
+    th = torch.empty((B, k), dtype=torch.float32, device=G.device)
+    check(lib.sed_ritz_f64(B, m, k, ptr(G.contiguous()), ptr(H.contiguous()), ptr(C), ptr(th), stream()), "ritz")
+    return C, th
+
+
+def lobpcg_residual(S, AS, lam, k):
+    """R (columns k .. 2k of S) = normalised, X-orthogonalised residual AX - X lam"""
+    B, N, ld = S.shape
+    nws = lib.sed_lobpcg_workspace_bytes(B, N, k)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=S.device)
+    check(lib.sed_lobpcg_residual_f32(B, N, k, ptr(S), ptr(AS), ld, ptr(lam), ptr(ws), nws, stream()), "lobpcg_residual")
+
+
+def lobpcg_update(S, AS, m, k, C):
+    B, N, ld = S.shape
+    check(lib.sed_lobpcg_update_f32(B, N, m, k, ptr(S), ptr(AS), ld, ptr(C), stream()), "lobpcg_update")
+
+
+def rank1_add(Y, d, t, alpha):
+    """Y [B,N,k] (column slice) += alpha d t^T"""
+    B, N, k = Y.shape
+    check(lib.sed_rank1_add_f32(B, N, k, _vptr(Y), Y.stride(1), ptr(d), ptr(t.contiguous()), float(alpha), stream()), "rank1_add")
 
 
 def knn_points_normals(x6, k, W=1.0):
@@ -165,7 +207,7 @@ def ms_bandwidth(X, K, min_bw=0.003):
     todo = None                                              # clouds left for the materialised path (None: all)
     # two MFMA sweeps + candidate lists, no N x N matrix (bandwidth_fused.hip); the materialised path below is the
     # fall-back (K beyond the fused kernel's range, clouds whose candidate lists overflowed)
-    if FUSED_KNN and D <= 128 and K <= lib.sed_ms_kth_fused_max_k(N) and B * ((N + 127) // 128) >= KTH_FUSED_MIN_BLOCKS:
+    if FUSED_KNN and D <= 160 and K <= lib.sed_ms_kth_fused_max_k(N) and B * ((N + 127) // 128) >= KTH_FUSED_MIN_BLOCKS:
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
         flag = torch.empty((B,), dtype=torch.int32, device=X.device)

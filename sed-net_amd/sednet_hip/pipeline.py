@@ -44,13 +44,16 @@ class SegmentationPipeline:
     _graphs = None
     _graph_ok = True
 
-    def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True, dist=None):
+    def __init__(self, model_type, model_inst, quantile=0.015, iterations=50, max_segments=50, fit=True, dist=None,
+                 hpnet=False):
         """dist: an initialised torch.distributed (world > 1) -> the guard loop's retry passes are balanced over the
-        ranks (every rank must then call the pipeline the same number of times)."""
+        ranks (every rank must then call the pipeline the same number of times). hpnet: the reference script's default
+        spectral re-weighting of the embedding between the instance model and the clustering (generate_predictions_aug.py:58,
+        :371-377; src/smooth_normal_matrix.hpnet_process): the embedding grows to 140 columns (160 padded)."""
         from src.mean_shift import MeanShift
         self.model_type, self.model_inst = model_type, model_inst
         self.quantile, self.iterations, self.S, self.fit = quantile, iterations, max_segments, fit
-        self.ms, self.dist = MeanShift(), dist
+        self.ms, self.dist, self.hpnet = MeanShift(), dist, hpnet
 
     def _forwards(self, x6, ev=None):
         """both models on x6 -> (log_prob, t_model, emb, edges, X, overflow flags)"""
@@ -186,6 +189,12 @@ class SegmentationPipeline:
             X = ops.row_normalize(embedding.float().contiguous(), embedding.shape[2])
         types = t_model if types is None else types.int().contiguous()
         ev.mark("instance_model")
+        if self.hpnet:
+            from src.smooth_normal_matrix import hpnet_process
+            wide = hpnet_process(emb if embedding is None else embedding.float(), x6[:, 0:3].transpose(1, 2).contiguous(),
+                                 x6[:, 3:6].transpose(1, 2).contiguous(), normal_smooth_w=0.5, CHUNK=1000)     # :59, :375
+            X = ops.row_normalize(wide.contiguous(), wide.shape[2])                                           # :377
+            ev.mark("hpnet")
         labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations, dist=self.dist)
         ev.mark("mean_shift")
         out = {"labels": labels, "types": types, "bw": bw, "n_labels": n_labels, "passes": passes, "edges": edges}

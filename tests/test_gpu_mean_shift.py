@@ -262,7 +262,10 @@ def test_chunked_schedule_other_widths(T):
         finally:
             ops.ms_set_variant("auto")
         auto = ops.ms_iterate(X, bw, 50).cpu().numpy()[0]
-        np.testing.assert_array_equal(auto, res["chunked50"])               # one cloud of this size: auto = chunked
+        if d == 64:
+            np.testing.assert_array_equal(auto, res["chunked50"])           # one cloud of this size: auto = key-chunked fp32
+        else:                                                               # d = 160 (round 3): auto = key-chunked split-fp16
+            np.testing.assert_allclose(auto, res["chunked50"], atol=2e-5)
         np.testing.assert_allclose(res["batched50"], res["chunked50"], atol=2e-5)
         x64 = X[0].cpu().numpy().astype(np.float64)
         rows = np.arange(0, N, 61)
@@ -588,3 +591,54 @@ def test_full_size_properties(T):
     sub = oms.mean_shift_iterations(X, float(bw), 1)[:256]
     got1, _ = ms.mean_shift_(dev(T, X), float(bw), iterations=1)
     np.testing.assert_allclose(got1.cpu().numpy()[:256], sub, atol=2e-6)
+
+
+def test_hpnet_width_runs_the_split_fp16_kernels(T):
+    """d = 140 -> 160 (the HPNet-widened embedding, generate_predictions_aug.py:371-377): the fused bandwidth
+    (no N x N matrix) is bit-identical to the materialised path at this width too, and the mean-shift iterations run on the
+    fp16 matrix pipe (ms_iterate_f16w_kernel<5, ...>: ten k-steps, five feature tiles; whole sweeps + the combine kernel) --
+    against the exact fp32 kernel, against fp64 on a row sample, with one and two weight digits, many and few clouds per call
+    (key-chunked), ragged N, a cloud with non-unit rows (flagged -> exact fp32 kernel) in the batch."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import MsOptions, lib
+    N = 6003
+    Xs = np.stack([synth.clustered_embedding(N=N, d=140, n_clusters=8 + c, sigma=0.02, seed=160 + c)[0] for c in range(3)])
+    X = ops.pad_features(dev(T, Xs))
+    assert X.shape[2] == 160
+    ops.FUSED_STATS.update(fused=0, fallback=0)
+    bw = ops.ms_bandwidth(X, 90, 0.003)
+    assert ops.FUSED_STATS == {"fused": 3, "fallback": 0}
+    try:
+        ops.KTH_FUSED_MIN_BLOCKS = 1 << 30
+        assert T.equal(ops.ms_bandwidth(X, 90, 0.003), bw)                   # materialised path: the same bits
+    finally:
+        ops.KTH_FUSED_MIN_BLOCKS = 0
+    assert lib.sed_ms_iterate_plan(3, N, 160, MsOptions(0, 0, 0)) == 5 and lib.sed_ms_iterate_plan(64, N, 160, MsOptions(0, 0, 0)) == 4
+    res = {}
+    try:
+        for v in ("batched", "f16", "f16/1", "f16c", "f16c/1"):
+            set_schedule(v)
+            res[v] = ops.ms_iterate(X, bw, 50).cpu().numpy()
+            res[v + "@1"] = ops.ms_iterate(X, bw, 1).cpu().numpy()
+        set_schedule("f16")
+        Xbad = X.clone(); Xbad[1] *= 1.1                                    # |x|^2 - 1 = 0.21 > b^2: flagged
+        bad = ops.ms_iterate(Xbad, bw, 5).cpu().numpy()
+        set_schedule("batched")
+        bad_ref = ops.ms_iterate(Xbad, bw, 5).cpu().numpy()
+    finally:
+        reset_schedule()
+    for v in ("f16", "f16/1", "f16c", "f16c/1"):
+        np.testing.assert_allclose(res[v], res["batched"], atol=3e-5, err_msg=v)
+        np.testing.assert_allclose(np.linalg.norm(res[v], axis=2), 1.0, atol=1e-6)
+        assert (res[v][:, :, 140:] == 0).all()                              # the padding columns stay zero
+    np.testing.assert_allclose(res["f16"], res["f16/1"], atol=5e-6)
+    x64 = X[0].cpu().numpy().astype(np.float64)
+    rows = np.arange(0, N, 53)
+    b = float(bw[0])
+    p = np.exp(-0.5 * (2.0 - 2.0 * x64[rows] @ x64.T) / (b * b))
+    ref = p @ x64 / p.sum(1, keepdims=True)
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    for v in ("f16@1", "f16/1@1", "f16c@1"):
+        np.testing.assert_allclose(res[v][0][rows], ref, atol=3e-6, err_msg=v)
+    np.testing.assert_array_equal(bad[1], bad_ref[1])                       # flagged cloud: the exact fp32 kernel's bits
+    np.testing.assert_allclose(bad[0], bad_ref[0], atol=1e-5)

@@ -841,7 +841,7 @@ int ms_f16_launch(int B, int N, int d, int iters, const float* bw, const float* 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
-                         float margin, unsigned long long* stats, int digits, hipStream_t stream);
+                         float margin, unsigned long long* stats, int digits, int form, hipStream_t stream);
 
 static int ms_combine_launch(const float* partO, const float* partS, const float* Qin, float* Qout, size_t rows, int S,
                              int d, int N, int* lowq, hipStream_t stream) {
@@ -1005,15 +1005,20 @@ extern "C" size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N) {
 extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X,
                                              float* newX, float skip_below, const float* tile_ref,
                                              const float* tile_cosalpha, float margin, void* workspace,
-                                             size_t workspace_bytes, void* stats, int weight_digits, hipStream_t stream) {
+                                             size_t workspace_bytes, void* stats, int weight_digits, int form,
+                                             hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !tile_ref || !tile_cosalpha ||
-        margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2)
+        margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2 || form < 0 || form > 3)
         return SED_EINVAL;
     if (d != 128) return SED_EUNSUPPORTED;
     if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
+    if (iters == 0) {                                       // zero iterations: the rows themselves
+        const hipError_t e = hipMemcpyAsync(newX, X, (size_t)B * N * d * sizeof(float), hipMemcpyDeviceToDevice, stream);
+        return e == hipSuccess ? SED_OK : (int)e;
+    }
     int* flags = nullptr;
     const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
-                                        margin, (unsigned long long*)stats, weight_digits == 1 ? 1 : 2, stream);
+                                        margin, (unsigned long long*)stats, weight_digits == 1 ? 1 : 2, form, stream);
     if (rc != SED_OK) return rc;
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
     static bool attr_fb = false;

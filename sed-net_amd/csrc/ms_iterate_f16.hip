@@ -1023,6 +1023,573 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_f16w_kernel(const float* __
     // (iters == 0 never reaches this kernel: sed_ms_iterate_ws_f32 only plans the split-fp16 schedules for iters > 0)
 }
 
+#ifndef F16S_NBUF
+#define F16S_NBUF 3                                    // stage buffers of the sparse kernel (4 fit -- 4 x 37 KiB + 7 KiB of tables <= 160 KiB -- and change nothing: 51.1 vs 50.5 ms)
+#endif
+constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
+
+constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
+constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
+constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
+
+// ------------------------------------------------------------------------------------------------------------
+// Block-sparse schedule, round 3 form (ms_iterate_d128_f16x_kernel): the same skipping RULE as ms_iterate_d128_f16s_kernel below
+// -- every tile has two unit references with cos(alpha); a key tile is visited by a workgroup only if a query of the workgroup is
+// within theta + alpha + margin of one of the tile's references -- on the pipeline of the dense kernel ms_iterate_f16w_kernel:
+// 64 queries per wave, row-major 17 KiB stage images, software pipeline inside the wave, one barrier per listed stage. What
+// changes against the dense kernel is only WHICH stages a workgroup copies and computes: the entries of its stage list (rebuilt
+// when a query has moved), walked in alternating direction; what changes against the round-2 kernel: small workgroups (NW = 2
+// waves = 128 queries, two per CU) whose waves ALL compute every listed stage (no per-wave skipping inside the list: a skipped
+// block saved its MFMAs but left the pipeline in pieces -- 0.35 of the matrix roof against the dense pipeline's 0.56).
+constexpr int F16X_NBUF = 3;
+template <int NW, bool PL = true>
+__global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
+    int* __restrict__ queue, int* __restrict__ item_stages) {
+    constexpr int NT = 4;
+    constexpr int MAXW = F16S_MAXW, QB = 64 * NW;         // query rows per workgroup
+    constexpr int REFB = 9216;                            // the first 9 DMA pieces of an image hold its 8704-byte head plane
+    __shared__ unsigned long long wmask[NW][MAXW];
+    __shared__ int slist[512];
+    __shared__ float wmoved[NW];
+    __shared__ int ns_sh, item_sh;
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW];
+    using L = StageLayoutD<NT>;
+    constexpr int D = L::D, KS = 2 * NT, NSTEP = 4 * NT;  // k-steps of the first product, operand steps of a block
+    constexpr int XROW = L::XROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int NBUF = 3;
+    constexpr int RD = F16W_RING_DISTANCE;             // one step ahead = 6 / 4 MFMAs (192 / 128 matrix cycles) per operand pair
+    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [3][STAGE]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    // Persistent workgroups (the grid is the number of resident workgroups, not the number of work items): an item = 64 NW
+    // query rows of one cloud for all iterations, and items take 6 .. 40 ms depending on how many stages their queries see --
+    // in EVERY cloud (the queries inside its largest cluster list most of it). Left to the hardware dispatcher, which hands
+    // workgroups out in order, slots sat idle for milliseconds behind a busy shader engine and the launch ended on a 35 ms
+    // tail of long items (84 % of the slots busy on trained embeddings). Here a slot that has finished takes the next item of
+    // `item_list` itself: items sorted by descending length of their first stage list (ms_sparse_item_order_kernel; counted by
+    // a first launch of this kernel with item_stages != NULL, which stops after building the lists), so the launch ends on
+    // its shortest items. item_list == NULL: items in natural order.
+    const int nbx = (N + QB - 1) / QB;
+    for (;;) {
+    __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
+    if (tid == 0) {
+        const int j = atomicAdd(queue, 1);
+        item_sh = j >= nitems ? -1 : item_list ? item_list[j] : ((j / nbx) << 8) | (j % nbx);
+    }
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(item_sh);
+    if (item < 0) break;
+    const int bx = item & 0xff;
+    const int cloud = item >> 8;
+    [&]() __attribute__((always_inline)) {
+#ifdef F16X_CLOCKS
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;
+    const float* Xc = X + (size_t)cloud * N * D;
+    const int nst = (N + 31) >> 5;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    constexpr int REFG = NBUF * STAGE / REFB;             // reference head planes per LDS load
+    int qrow[2], qrow_c[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        qrow[g] = bx * QB + wave * 64 + g * 32 + li;
+        qrow_c[g] = qrow[g] < N ? qrow[g] : N - 1;
+    }
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    const float TMIN = LOG2_SCALE_P - 75.0f * 1.44269504088896340736f;
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 64 * NW) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + rho], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
+
+    h16x8 qh[2][KS], ql[2][KS];
+    auto split_q = [&](int g, int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[g][ks][i] = h;
+            ql[g][ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c[g] * D + 16 * ks + 8 * hi + 4 * q);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[4 * q + u] = t[u] * SCALE_X;
+            }
+            split_q(g, ks, v);
+        }
+
+    // the 17 DMA pieces (1 KiB each) of a stage image are dealt round-robin to the waves
+    static_assert(NPIECE == 17, "17 pieces");
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+            const int pc = wave + i * NW;
+            if (pc < NPIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024 + lane16),
+                                                 (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+    h16x8 fa[4], fb[4];
+    int xoff, toff;                                       // see ms_iterate_d128_f16r_kernel: same image rows, same permutation
+    auto refresh_offsets = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const int m = l & 31, h = l >> 5;
+        const int sig = 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3);
+        xoff = sig * XROW + h * 16;
+        const int i16 = l & 15;
+        toff = (4 * (i16 >> 2) + h) * XROW + 32 * ((l >> 4) & 1) + 8 * (i16 & 3);
+    };
+    refresh_offsets();
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
+    auto ring_load = [&](int t, const uint8_t* base) {
+        if (t < KS) {
+            fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+    f32x16 s_cur[2], s_next[2];
+    auto plain_first_product = [&](const uint8_t* base) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_cur[g][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const h16x8 a = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
+            const h16x8 l = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) s_cur[g] = mfma16(l, qh[g][t], s_cur[g]);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) s_cur[g] = mfma16(a, ql[g][t], s_cur[g]);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) s_cur[g] = mfma16(a, qh[g][t], s_cur[g]);
+        }
+    };
+
+    f32x16 o[2][NT];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
+    float rsum[2] = {0.f, 0.f};
+    int buf = 0;
+    i32x4 phv[2][2], plv[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_cur[g][r] = 0.f; s_next[g][r] = 0.f; }
+    unsigned long long n_listed = 0, n_remake = 0;        // statistics only
+    int ns = 0;                                           // entries of the workgroup's stage list
+    bool fwd = true;                                      // the list is walked in alternating direction (L2 reuse)
+    // list entries: one LDS word per block, fetched four blocks ahead
+    auto entry_raw = [&](int j) { return slist[fwd ? j : ns - 1 - j]; };
+    auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(entry_raw(j)); };
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;                   // entries n .. n + 3 of the running sweep (scalar registers)
+
+    // One block of the pipeline. HAS_NEXT: the block is followed by another one of the same sweep (whose first product runs here,
+    // under this block's weights). The blocks of a sweep form the INNER loop and the row update sits between sweeps, outside it:
+    // with everything in one flat loop the register allocator weighed the row update like the hot path and spilled inside it.
+    int n = 0;                                            // entries of this sweep done (the DMA runs three entries ahead)
+    auto block = [&](auto has_next_c) __attribute__((always_inline)) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        const uint8_t* base = lds + buf * STAGE;
+        const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+        const uint8_t* nbase = lds + nbuf * STAGE;
+        const uint8_t* n2base = lds + (nbuf == NBUF - 1 ? 0 : nbuf + 1) * STAGE;
+        const int key0 = q0 * 32;
+        const bool tail = key0 + 32 > N;
+        const int raw4 = n + 4 < ns ? entry_raw(n + 4) : 0;   // consumed at the end of the block
+        refresh_offsets();
+
+        auto weights2 = [&](int g, int t, auto tail_c) {
+            float p[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * t + u;
+                p[u] = __builtin_amdgcn_exp2f(fmaxf(fmaf(s_cur[g][r], K1, K0), TMIN));
+                if (decltype(tail_c)::value && key0 + sigma_row(mfma_row(r, hi)) >= N) p[u] = 0.f;
+                if (PL) rsum[g] += p[u];
+            }
+            const h16x2 h = {(h16)p[0], (h16)p[1]};
+            phv[g][t >> 2][t & 3] = __builtin_bit_cast(int, h);
+            if (PL) {
+                const h16x2 l = {(h16)(p[0] - (float)h[0]), (h16)(p[1] - (float)h[1])};
+                plv[g][t >> 2][t & 3] = __builtin_bit_cast(int, l);
+            } else {
+                rsum[g] += (float)h[0] + (float)h[1];
+            }
+        };
+
+        // ---- phase 1: first product of block n + 1 (both query groups) with the weights of block n between its MFMAs
+        auto phase1 = [&](auto tail_c) {
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s_next[0] = mfma16(fb[0], qh[0][0], z);
+                    s_next[1] = mfma16(fb[0], qh[1][0], z);
+                } else {
+                    s_next[0] = mfma16(fb[t & 3], qh[0][t], s_next[0]);
+                    s_next[1] = mfma16(fb[t & 3], qh[1][t], s_next[1]);
+                }
+                if (t < 8) weights2(0, t, tail_c);              // 16 accumulator rows = 8 pairs
+                s_next[0] = mfma16(fa[t & 3], ql[0][t], s_next[0]);
+                s_next[1] = mfma16(fa[t & 3], ql[1][t], s_next[1]);
+                if (t < 8) weights2(1, t, tail_c);
+                s_next[0] = mfma16(fa[t & 3], qh[0][t], s_next[0]);
+                s_next[1] = mfma16(fa[t & 3], qh[1][t], s_next[1]);
+                if (t + RD < KS) ring_load(t + RD, nbase);
+                else ring_load(t + RD, base);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (has_next) {
+            if (tail) phase1(std::true_type{});
+            else phase1(std::false_type{});
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_next[g][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {                          // (16 accumulator rows = 8 pairs, whatever the feature width)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (tail) weights2(g, t, std::true_type{});
+                    else weights2(g, t, std::false_type{});
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+                if (t + RD >= KS) ring_load(t + RD, base);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- phase 2: second product of block n, both query groups per operand read. (Every wave computes every listed stage.
+        // Skipping the MFMAs of a wave whose weights all rounded to zero -- per 32-query group, per operand step or for the whole
+        // phase -- was tried three ways and lost every time, 324 .. 390 ms against 260: hipcc 7.2 then moves the accumulators
+        // between the two register files around the conditional MFMAs and spills inside the loop.)
+#pragma unroll
+        for (int t = KS; t < NSTEP; ++t) {
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) o[g][c] = mfma16(fb[t & 3], __builtin_bit_cast(h16x8, phv[g][j]), o[g][c]);
+            if (PL) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) o[g][c] = mfma16(fa[t & 3], __builtin_bit_cast(h16x8, plv[g][j]), o[g][c]);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) o[g][c] = mfma16(fa[t & 3], __builtin_bit_cast(h16x8, phv[g][j]), o[g][c]);
+            if (t + RD < NSTEP) ring_load(t + RD, base);
+            else if (n + 2 < ns) ring_load(t + RD - NSTEP, n2base);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == NSTEP - 1 - RD) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (n + 3 < ns) stage_dma(q3, buf);
+            }
+        }
+
+        buf = nbuf;
+        ++n;
+        q0 = q1; q1 = q2; q2 = q3;
+        q3 = __builtin_amdgcn_readfirstlane(raw4);
+        if constexpr (has_next) {
+            s_cur[0] = s_next[0];
+            s_cur[1] = s_next[1];
+        }
+    };
+
+    // Every workgroup walks the UNION of its waves' stage lists with the dense kernel's pipeline (all its waves compute every listed
+    // stage: a stage one wave needs and the other does not costs that wave a block of MFMAs whose weights come out <= e^skip, but
+    // the pipeline stays the dense kernel's -- 0.56 of the matrix roof against 0.35 for the per-wave skipping of the round-2 kernel;
+    // with 128-query workgroups the union holds 56 % of the stages on trained embeddings where a 32-query wave needs 48 %).
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack). The rows at mask time are parked in the output rows.
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous sweep's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) mx = fmaxf(mx, wmoved[w2]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (qrow[g] < N) {                       // remember where the masks were made: the row's slot of the output
+                    float* keep = newX + ((size_t)cloud * N + qrow[g]) * 128;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v0[u] = ((float)qh[g][ks][u] + (float)ql[g][ks][u]) * UNSCALE_Q;
+                            v1[u] = ((float)qh[g][ks][4 + u] + (float)ql[g][ks][4 + u]) * UNSCALE_Q;
+                        }
+                        *(f32x4*)(keep + 16 * ks + 8 * hi) = v0;          // Q operand of k-step ks: features 16 ks + 8 hi + i; the same
+                        *(f32x4*)(keep + 16 * ks + 8 * hi + 4) = v1;      // lane reads them back in this order at the row update
+                    }
+                }
+            // ---- this wave's 64 queries against all tile references -> its stage mask
+            for (int g0 = 0; g0 < nrs; g0 += REFG) {
+                const int ng = min(REFG, nrs - g0);
+                if (g0 > 0) __syncthreads();                  // every wave is done with the previous group's planes
+                for (int pc = wave; pc < ng * 9; pc += NW) {  // 1 KiB pieces: image pc / 9, piece pc % 9
+                    const int im = pc / 9, piece = pc - 9 * im;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                        (__attribute__((address_space(3))) void*)(lds + im * REFB + piece * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int im = 0; im < ng; ++im) {
+                    const uint8_t* rbase = lds + im * REFB + OFF_XH + li * XROW + hi * 16;     // references in natural row order
+                    unsigned word = 0;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        f32x16 sr;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[g][t], sr);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * q4 + 4 * hi);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * q4 + u] > th[u]);
+                                word |= ((unsigned)bal != 0u ? 1u : 0u) << (8 * q4 + u);              // tile row of lane half 0
+                                word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << (8 * q4 + u + 4);  // ... of lane half 1
+                            }
+                        }
+                    }
+                    if (lane == 0) {                                  // a tile is needed if either of its references is near
+                        unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                        *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                    }
+                }
+            }
+            if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
+            __syncthreads();
+            // ---- the workgroup's stage list, ascending (wave 0: one 64-bit word of the union at a time)
+            if (wave == 0) {
+                int base = 0;
+                for (int w2 = 0; w2 < (nst + 63) >> 6; ++w2) {
+                    unsigned long long any = 0ull;
+#pragma unroll
+                    for (int v = 0; v < NW; ++v) any |= wmask[v][w2];
+                    if ((any >> lane) & 1ull) slist[base + __builtin_popcountll(any & ((1ull << lane) - 1ull))] = 64 * w2 + lane;
+                    base += __builtin_popcountll(any);
+                }
+                if (lane == 0) ns_sh = base;
+            }
+            __syncthreads();
+            ns = __builtin_amdgcn_readfirstlane(ns_sh);
+            ++n_remake;
+            if (item_stages != nullptr) {                 // counting launch: the length of the first list is all that is wanted
+                if (tid == 0) item_stages[cloud * nbx + bx] = ns;
+                return;
+            }
+        }   // remake
+        n_listed += ns;
+        // ---- prime the copy pipeline of this sweep: entries 0 .. 2, first product of entry 0, operands of entry 1
+        fwd = (it & 1) == 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < ns) stage_dma(entry(j), j);
+        q0 = ns > 0 ? entry(0) : 0;
+        q1 = ns > 1 ? entry(1) : 0;
+        q2 = ns > 2 ? entry(2) : 0;
+        q3 = ns > 3 ? entry(3) : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        refresh_offsets();
+        buf = 0;
+        n = 0;
+        if (ns > 0) plain_first_product(lds);
+        if (ns > 1) {
+#pragma unroll
+            for (int t = 0; t < RD; ++t) ring_load(t, lds + STAGE);
+        }
+        for (int i = 0; i + 1 < ns; ++i) block(std::true_type{});
+        if (ns > 0) block(std::false_type{});
+        float wm = 0.f;
+        // ---- end of a sweep: row update (mean_shift.py:70-77), one query group after the other
+        bool low = false;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            // (the two groups are independent; the order only steers hipcc 7.2's register allocator: with this one both
+            // instantiations come out at 0 spilled registers / 0 bytes of scratch, with the other one 24 resp. 48 are spilled)
+            const int g = PL ? 1 - gi : gi;
+            const float rs = rsum[g] + xor32(rsum[g]);
+            const float Dinv = UNSCALE_O / rs;
+            // (one feature tile at a time: 16 values of the current Q live beside the accumulators, not 64 -- the kernel must not
+            // spill; the additions into n2 keep the order of the 8-wave kernel: tile by tile, register by register)
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                float qacc[16];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float e0 = ((float)qh[g][2 * c + j][u] + (float)ql[g][2 * c + j][u]) * UNSCALE_Q;
+                        const float e1 = ((float)qh[g][2 * c + j][4 + u] + (float)ql[g][2 * c + j][4 + u]) * UNSCALE_Q;
+                        const float keep = hi ? e1 : e0, send = hi ? e0 : e1;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        qacc[8 * j + u] = hi ? recv : keep;
+                        qacc[8 * j + 4 + u] = hi ? keep : recv;
+                    }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float q = qacc[r];
+                    const float m = o[g][c][r] * Dinv - q;
+                    const float nq = q + m;
+                    o[g][c][r] = nq;
+                    n2 += nq * nq;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            n2 += xor32(n2);
+            const float nrm = sqrtf(n2);
+            if (nrm < 0.5f) low = true;
+            if (it == iters - 1) {
+                // (row index and output address recomputed from a lane id the compiler cannot hoist: addresses formed at kernel
+                // entry would live -- and spill -- across the whole launch)
+                int l;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                const int qr = bx * QB + wave * 64 + g * 32 + (l & 31), hl = l >> 5;
+                if (qr < N) {
+                    float* out = newX + ((size_t)cloud * N + qr) * D;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            f32x4 v = {o[g][c][4 * q4] / nrm, o[g][c][4 * q4 + 1] / nrm, o[g][c][4 * q4 + 2] / nrm,
+                                       o[g][c][4 * q4 + 3] / nrm};
+                            *(f32x4*)(out + 32 * c + 8 * q4 + 4 * hl) = v;
+                        }
+                }
+            } else {
+                // new Q operand + how far the new row is from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
+                float ch2 = 0.f;
+                int l2;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+                const int qr2 = bx * QB + wave * 64 + g * 32 + (l2 & 31);
+                const float* kept = newX + ((size_t)cloud * N + (qr2 < N ? qr2 : N - 1)) * 128 + 8 * (l2 >> 5);
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float a = (o[g][c][8 * j + u] / nrm) * SCALE_X, bq = (o[g][c][8 * j + 4 + u] / nrm) * SCALE_X;
+                            const float keep = hi ? bq : a, send = hi ? a : bq;
+                            const float recv = __shfl_xor(send, 32, 64);
+                            v[u] = hi ? recv : keep;
+                            v[4 + u] = hi ? keep : recv;
+                        }
+                        const f32x4 k0 = *(const f32x4*)(kept + 16 * (2 * c + j));
+                        const f32x4 k1 = *(const f32x4*)(kept + 16 * (2 * c + j) + 4);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d0 = v[u] * UNSCALE_Q - k0[u], d1 = v[4 + u] * UNSCALE_Q - k1[u];
+                            ch2 = fmaf(d0, d0, fmaf(d1, d1, ch2));
+                        }
+                        split_q(g, 2 * c + j, v);
+                    }
+                if (qr2 >= N) ch2 = 0.f;
+                ch2 += xor32(ch2);
+                float w1 = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) w1 = fmaxf(w1, __shfl_xor(w1, off, 64));
+                wm = fmaxf(wm, w1);
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[g][c][r] = 0.f;
+                rsum[g] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);             // one query group after the other: nothing of the second is started early
+        }
+        if (!PL && lowq != nullptr && low) lowq[cloud] = 1;
+        if (it + 1 < iters && lane == 0) wmoved[wave] = wm;   // read after the barrier that opens the next sweep
+    }
+    if (stats && lane == 0) {
+        // [0] stage visits of workgroups, [1] first and [2] second products of 32-query groups (this kernel: every wave computes
+        // every listed stage), [3] the dense count of 32-query groups x stages x iterations, [4] mask / list constructions
+        if (wave == 0) atomicAdd(stats + 0, n_listed);
+        atomicAdd(stats + 1, 2ull * n_listed);
+        atomicAdd(stats + 2, 2ull * n_listed);
+        atomicAdd(stats + 3, 2ull * (unsigned long long)nst * (unsigned long long)iters);
+        if (wave == 0) atomicAdd(stats + 4, n_remake);
+#ifdef F16X_CLOCKS
+        if (wave == 0) { atomicAdd(stats + 5, __builtin_amdgcn_s_memrealtime() - t_start); atomicMax(stats + 6, __builtin_amdgcn_s_memrealtime()); atomicMin(stats + 7, t_start);
+            const int orig = cloud * nbx + bx;
+            stats[8 + 4 * orig] = t_start; stats[9 + 4 * orig] = __builtin_amdgcn_s_memrealtime();
+            stats[10 + 4 * orig] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); stats[11 + 4 * orig] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }
+#endif
+    }
+    }();
+    }   // work items
+}
+
+
 // ------------------------------------------------------------------------------------------------------------
 // Block-sparse schedule on the pipelined split-fp16 kernel (round 2; its fp32 predecessor: tools/experiments/ms_sparse_fp32.hip).
 // Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure, together with two unit reference
@@ -1045,21 +1612,13 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_f16w_kernel(const float* __
 // The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
 // direction so that an iteration starts on the stages the previous one left in L2.
 // What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
-#ifndef F16S_NBUF
-#define F16S_NBUF 3                                    // stage buffers of the sparse kernel (4 fit -- 4 x 37 KiB + 7 KiB of tables <= 160 KiB -- and change nothing: 51.1 vs 50.5 ms)
-#endif
-constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
-
-constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
-constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
-constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
-
 template <bool STAGGER, bool PL = true>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
-    unsigned long long* __restrict__ stats, int* __restrict__ lowq = nullptr) {
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
+    int* __restrict__ queue, int* __restrict__ item_stages) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
@@ -1068,14 +1627,27 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     __shared__ unsigned long long wmask[8][MAXW];
     __shared__ int slist[512];
     __shared__ int wcount[8];
+    __shared__ int item_sh;
     __shared__ float wmoved[8];
     __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
     const bool late = STAGGER && wave >= 4;
-    int bx;
-    const int cloud = sed_xcd_cloud_block(&bx);
+    // persistent workgroups over a sorted item list: see ms_iterate_d128_f16x_kernel (an item here = 256 query rows of a cloud)
+    const int nbx = (N + 255) >> 8;
+    for (;;) {
+    __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
+    if (tid == 0) {
+        const int j = atomicAdd(queue, 1);
+        item_sh = j >= nitems ? -1 : item_list ? item_list[j] : ((j / nbx) << 8) | (j % nbx);
+    }
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(item_sh);
+    if (item < 0) break;
+    const int bx = item & 0xff;
+    const int cloud = item >> 8;
+    [&]() __attribute__((always_inline)) {
     if (flags[cloud]) return;
     if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
     const float* Xc = X + (size_t)cloud * N * 128;
@@ -1261,6 +1833,10 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         __syncthreads();
         ns = __builtin_amdgcn_readfirstlane(ns);
         ++n_remake;
+        if (item_stages != nullptr) {                     // counting launch: the length of the first list is all that is wanted
+            if (tid == 0) item_stages[cloud * nbx + bx] = ns;
+            return;
+        }
         }   // remake
         n_listed += ns;
 
@@ -1420,11 +1996,6 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             rsum = 0.f;
         }
     }
-    if (iters == 0 && qrow < N) {
-        float* out = newX + ((size_t)cloud * N + qrow) * 128;
-        const float* in = Xc + (size_t)qrow * 128;
-        for (int d = 4 * hi; d < 128; d += 8) *(f32x4*)(out + d) = *(const f32x4*)(in + d);
-    }
     if (stats && lane == 0) {
         // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
         // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
@@ -1434,6 +2005,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         atomicAdd(stats + 3, (unsigned long long)nst * (unsigned long long)iters);
         if (wave == 0) atomicAdd(stats + 4, n_remake);
     }
+    }();
+    }   // work items
 }
 
 }  // namespace
@@ -1609,32 +2182,143 @@ int ms_f16_chunked_launch(int B, int N, int d, int S, int iters, const float* bw
     return SED_OK;
 }
 
-// stage images of the sorted rows | flags | stage images of the tile references | scratch flags | cancel flags
+// stage images of the sorted rows | flags | stage images of the tile references | scratch flags | cancel flags | work queues
 size_t ms_f16_sparse_workspace_bytes(int B, int N) {
     const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
-    return f16_blob_bytes_4(B, N) + f16_blob_bytes_4(B, nref) + 3 * f16_flag_bytes(B);
+    return f16_blob_bytes_4(B, N) + f16_blob_bytes_4(B, nref) + 3 * f16_flag_bytes(B) +
+           (size_t)(64 + 2 * (size_t)B * ((N + 127) / 128)) * sizeof(int);      // + queue heads, first list lengths, item list
+}
+
+// Work items of the persistent block-sparse kernel in descending order of their first stage-list length (counting sort on
+// MS_ITEM_BUCKETS coarse length classes: inside a class the items keep their order -- cloud by cloud, so that the workgroups
+// running at the same time still stream mostly the same clouds through the L2s). One workgroup.
+constexpr int MS_ITEM_BUCKETS = 16;
+__global__ __launch_bounds__(1024) void ms_sparse_item_order_kernel(const int* __restrict__ item_stages, int nitems, int nbx, int nst,
+                                                                    int* __restrict__ item_list) {
+    __shared__ int count[MS_ITEM_BUCKETS], start[MS_ITEM_BUCKETS];
+    const int tid = threadIdx.x;
+    auto bucket = [&](int ns) { return MS_ITEM_BUCKETS - 1 - min(MS_ITEM_BUCKETS - 1, ns * MS_ITEM_BUCKETS / (nst + 1)); };
+    if (tid < MS_ITEM_BUCKETS) count[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nitems; i += 1024) atomicAdd(&count[bucket(item_stages[i])], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < MS_ITEM_BUCKETS; ++k) { start[k] = acc; acc += count[k]; }
+    }
+    __syncthreads();
+    // stable scatter, one class after the other: a block-wide running offset per pass of 1024 items
+    __shared__ int wsum[16], base_sh;
+    for (int k = 0; k < MS_ITEM_BUCKETS; ++k) {
+        if (count[k] == 0) continue;                      // (uniform: shared value)
+        if (tid == 0) base_sh = start[k];
+        __syncthreads();
+        for (int i0 = 0; i0 < nitems; i0 += 1024) {
+            const int i = i0 + tid;
+            const bool in = i < nitems && bucket(item_stages[i]) == k;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+            const int lane = tid & 63, w = tid >> 6;
+            if (lane == 0) wsum[w] = __builtin_popcountll(bal);
+            __syncthreads();
+            int off = base_sh;
+            for (int v = 0; v < w; ++v) off += wsum[v];
+            if (in) item_list[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = ((i / nbx) << 8) | (i % nbx);
+            __syncthreads();
+            if (tid == 0) {
+                int t = 0;
+                for (int v = 0; v < 16; ++v) t += wsum[v];
+                base_sh += t;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
 // row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, 128] unit vectors (unused rows zero),
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N); stats (optional, device, 5 x u64, accumulated; the redo pass is not counted).
+template <int NW>
+static int f16x_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                       float margin, unsigned long long* stats, int digits, int* sched, hipStream_t stream) {
+    using L = StageLayoutN;
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
+    constexpr int sm = F16X_NBUF * L::STAGE;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16x_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16x_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int nbx = (N + 64 * NW - 1) / (64 * NW);
+    if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
+    static int slots = 0;                                  // resident workgroups: 512 registers per wave = one wave per SIMD
+    if (!slots) {
+        int dev = 0, cus = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+        slots = cus * (4 / NW);
+    }
+    const int nitems = nbx * B;
+    const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
+    int* queue = sched;                                    // [4] queue heads | [nitems] first list lengths | [nitems] item list
+    int* item_stages = sched + 4;
+    int* item_list = item_stages + nitems;
+    hipError_t e = hipMemsetAsync(sched, 0, (size_t)(4 + nitems) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+    ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    // first launch: every item builds its first stage list and reports its length; then the items are sorted by it
+    ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
+                                                                         tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr,
+                                                                         queue, item_stages);
+    ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, nitems, nbx, nst, item_list);
+    if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
+        ms_iterate_d128_f16x_kernel<NW, false><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
+                                                                              tile_cosalpha, margin, stats, lowq, nitems, item_list,
+                                                                              queue + 1, nullptr);
+        ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
+                                                                             tile_cosalpha, margin, nullptr, lowq, nitems, item_list,
+                                                                             queue + 2, nullptr);
+    } else
+        ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
+                                                                             tile_cosalpha, margin, stats, nullptr, nitems, item_list,
+                                                                             queue + 1, nullptr);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// form: 1 = round 2's 8-wave kernel on four-plane images (ms_iterate_d128_f16s_kernel); 2 / 3 = the 64-queries-per-wave kernel on
+// row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 0 = default
+constexpr int MS_SPARSE_DEFAULT_FORM = 2;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
-                         float margin, unsigned long long* stats, int digits, hipStream_t stream) {
+                         float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
     using L = StageLayout<32>;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
+    if (form == 0) form = MS_SPARSE_DEFAULT_FORM;
     uint8_t* blob = (uint8_t*)workspace;
     int* flags = (int*)(blob + f16_blob_bytes_4(B, N));
     uint8_t* refblob = (uint8_t*)flags + f16_flag_bytes(B);
     int* flags2 = (int*)(refblob + f16_blob_bytes_4(B, nrs * 32));
     int* lowq = (int*)((uint8_t*)flags2 + f16_flag_bytes(B));           // clouds whose weighted means cancel (heads-only pass)
+    int* sched = (int*)((uint8_t*)lowq + f16_flag_bytes(B));
     *flags_out = flags;
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    if (form == 2)       // (the workspace is sized for the four-plane images: the row-major ones use the same carve-up)
+        return f16x_launch<2>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                              stats, digits, sched, stream);
+    if (form == 3)
+        return f16x_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                              stats, digits, sched, stream);
     static bool attr = false;
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
@@ -1647,17 +2331,38 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    const dim3 grid((N + 255) / 256, B);
+    const int nbx = (N + 255) / 256, nitems = nbx * B;
+    if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
+    static int slots = 0;                                  // resident workgroups: one of 512 threads per CU
+    if (!slots) {
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
+    int* queue = sched;                                    // [4] queue heads | [nitems] first list lengths | [nitems] item list
+    int* item_stages = sched + 4;
+    int* item_list = item_stages + nitems;
+    e = hipMemsetAsync(sched, 0, (size_t)(4 + nitems) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
+        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, queue,
+        item_stages);
+    ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, nitems, nbx, nst, item_list);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
         ms_iterate_d128_f16s_kernel<true, false><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, item_list, queue + 1,
+            nullptr);
         ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, item_list, queue + 2,
+            nullptr);
     } else
         ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, item_list, queue + 1,
+            nullptr);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -246,6 +246,7 @@ MS_SPARSE_SKIP = -30.0
 # kernel could win on the widest clouds (134 + 177 ms against 249 ms for all 64 sparse). Unstructured rows sit at 1.0.
 MS_SPARSE_MAX_NEAR = 0.6
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
+MS_SPARSE_FORM = 0              # kernel form of the block-sparse schedule: 0 = library default, 1 = round 2's, 2 / 3 = round 3's
 MS_SPARSE_COUNTERS = None       # bench.py: an int64 [5] device tensor the block-sparse kernel adds its visit counts to
 # Options of the iteration kernels. They are the WRAPPER's state, handed to the library with every call (sed_ms_options_t);
 # libsedhip.so itself keeps none. CONFIG_EPOCH counts changes of any kernel-selection switch of this module, so that
@@ -397,7 +398,8 @@ def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
         stats = MS_SPARSE_COUNTERS
     check(lib.sed_ms_iterate_bounds_f16_f32(B, N, D, int(iters), ptr(bw), ptr(Xs), ptr(outs), float(skip_below),
                                             ptr(prep["ref"]), ptr(prep["cosalpha"]), float(margin), ptr(ws), nws,
-                                            ptr(stats) if stats is not None else None, _MS_WEIGHT_DIGITS, stream()),
+                                            ptr(stats) if stats is not None else None, _MS_WEIGHT_DIGITS, int(MS_SPARSE_FORM),
+                                            stream()),
           "ms_iterate_bounds_f16")
     if TIMERS is not None:
         ev1.record()

@@ -23,16 +23,22 @@ def t(fn):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1), r
-for skip in (-30.0, -25.0, -20.0):
-    stats = torch.zeros(5, dtype=torch.int64, device=dev)
-    ms_, out = t(lambda: ops.ms_iterate_sparse(X, bw, 50, skip, stats=stats))
-    c = stats.cpu().numpy().astype(float) / 2
-    prep_ms, prep = t(lambda: ops.ms_sparse_prepare(X))
-    print(f"skip {skip}: sparse all {B} clouds {ms_:.1f} ms (prep {prep_ms:.1f}); stage visits {c[0] / (c[3] / 8):.3f} first {c[1] / c[3]:.3f} second {c[2] / c[3]:.3f} of dense; rebuilds/wg {c[4] / (B * 40):.1f}")
 ops.ms_set_variant("f16")
 dms, dense = t(lambda: ops.ms_iterate(X, bw, 50))
 ops.ms_set_variant("auto")
-print(f"dense all {B} clouds {dms:.1f} ms; max |sparse(-30) - dense| {(ops.ms_iterate_sparse(X, bw, 50, -30.0) - dense).abs().max().item():.2e}")
+print(f"dense all {B} clouds {dms:.1f} ms")
+prep_ms, prep = t(lambda: ops.ms_sparse_prepare(X))
+for form, groups_per_wg in ((1, 8), (2, 4), (3, 8)):
+    ops.MS_SPARSE_FORM = form
+    for skip in (-30.0,) if form != 2 else (-30.0, -25.0):
+        stats = torch.zeros(5, dtype=torch.int64, device=dev)
+        ms_, out = t(lambda: ops.ms_iterate_sparse(X, bw, 50, skip, stats=stats))
+        c = stats.cpu().numpy().astype(float) / 2
+        err = (out - dense).abs()
+        print(f"form {form} skip {skip}: sparse all {B} clouds {ms_:.1f} ms (prep {prep_ms:.1f}); stage visits {c[0] * groups_per_wg / c[3]:.3f} "
+              f"first {c[1] / c[3]:.3f} second {c[2] / c[3]:.3f} of dense; rebuilds per workgroup {c[4] * groups_per_wg * 32 / (B * 10000):.1f}; "
+              f"vs dense: max {err.max().item():.2e} median-of-cloud-max {err.amax((1, 2)).median().item():.2e}")
+ops.MS_SPARSE_FORM = 0
 # per-cloud sparse time vs near fraction
 order = np.argsort(near)
 for lo in range(0, B, 16):

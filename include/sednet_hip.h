@@ -169,6 +169,16 @@ int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* b
                                   float skip_below, const float* tile_ref, const float* tile_cosalpha, float margin,
                                   void* workspace, size_t workspace_bytes, void* stats, int weight_digits, int form,
                                   sed_stream_t stream);
+/* Preparation of the block-sparse schedule, all on the device (ms_sparse_prep.hip): P <= 64 farthest-point pivots among every
+ * stride-th row, one k-means step, single-linkage super-groups of the means (merge_angle, radians), rows stable-sorted by
+ * (super-group, group) -> order [B,N] (sorted position -> row), Xs [B,N,128] the rows in that order, and per 32-row tile two
+ * references + cos(alpha) in the layout sed_ms_iterate_bounds_f16_f32 takes. Deterministic (integer atomics, sums in row order).
+ * sed_unsort_rows_f32: out[b, order[b,i]] = in[b,i] -- the result back in the caller's row order. d = 128, N <= 16 384. */
+size_t sed_ms_sparse_prepare_workspace_bytes(int B, int N, int P);
+int sed_ms_sparse_prepare_f32(int B, int N, int d, int P, int stride, float merge_angle, const float* X, int* order, float* Xs,
+                              float* tile_ref, float* tile_cosalpha, void* workspace, size_t workspace_bytes,
+                              sed_stream_t stream);
+int sed_unsort_rows_f32(int B, int N, int d, const float* in, const int* order, float* out, sed_stream_t stream);
 /* non-max suppression + labels, no host round trip.           src/mean_shift.py:139-179 (nms)
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
  * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */

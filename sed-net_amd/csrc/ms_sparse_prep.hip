@@ -3,6 +3,7 @@
 // scheduled is /root/reference/src/mean_shift.py:45-79; nothing here changes it -- any row order and any unit references are
 // CORRECT, they only decide how many 32 x 32 blocks the iteration kernel can prove negligible and skip.
 #include "common.h"
+#include "split16.h"
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -86,6 +87,334 @@ extern "C" int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const 
     if (B <= 0 || N <= 0 || stride <= 0 || P <= 0 || !X || !picks || !picked) return SED_EINVAL;
     if (d != 128 || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride) return SED_EUNSUPPORTED;
     fps_pivots_kernel<<<B, 1024, 0, stream>>>(X, N, stride, P, picks, picked);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// The rest of the preparation (round 3: these were torch.bmm / one_hot / sort / gather calls in ops.ms_pivot_order and
+// ops.ms_sparse_prepare): rows join their nearest pivot, pivot groups are replaced by their normalised means (one k-means step),
+// rows join the nearest mean, means closer than `merge_angle` are linked into super-groups (single linkage), rows are
+// stable-sorted by (super-group, group), and every 32-row tile of the sorted rows gets two reference directions with the
+// cosine of the cap that holds its rows. Everything is deterministic: integer atomics only, sums in row order.
+namespace {
+
+constexpr int PREP_D = 128, PREP_P = 64;
+
+// rows -> index of the pivot with the largest dot product (ties: the lowest index), on the matrix pipe: scores [pivot][row] =
+// P X^T with both operands rounded to fp16 (|error| <= 1e-3 on a dot product of unit vectors -- it moves a row that is about
+// equally far from two pivots to the other one, and ANY grouping is a valid input of the steps that follow; same bits in every
+// run). Wave = 32 rows x 64 pivots (two 32 x 32 x 16 MFMA tiles over 8 k-steps), lane = one row, workgroup = 128 rows.
+__global__ __launch_bounds__(256) void prep_assign_kernel(const float* __restrict__ X, const float* __restrict__ piv, int N, int P,
+                                                          int* __restrict__ grp, int* __restrict__ counts) {
+    __shared__ int hist[PREP_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.y, row = blockIdx.x * 128 + wave * 32 + li;
+    const float* Xc = X + (size_t)cloud * N * PREP_D;
+    const float* pc = piv + (size_t)cloud * P * PREP_D;
+    if (tid < PREP_P) hist[tid] = 0;
+    auto load8 = [&](const float* src) {
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+        h16x8 v = {(h16)a[0], (h16)a[1], (h16)a[2], (h16)a[3], (h16)b[0], (h16)b[1], (h16)b[2], (h16)b[3]};
+        return v;
+    };
+    const int rc = row < N ? row : N - 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const h16x8 xb = load8(Xc + (size_t)rc * PREP_D + 16 * ks + 8 * hi);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int pm = 32 * t + li;
+            const h16x8 pa = load8(pc + (size_t)(pm < P ? pm : P - 1) * PREP_D + 16 * ks + 8 * hi);
+            acc[t] = mfma16(pa, xb, acc[t]);
+        }
+    }
+    float best = -3.0e38f;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pm = 32 * t + mfma_row(r, hi);
+            const float v = acc[t][r];
+            if (pm < P && (v > best || (v == best && pm < besti))) { best = v; besti = pm; }
+        }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(besti, 32, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    if (besti == 0x7fffffff) besti = 0;                    // a NaN row: any group will do
+    __syncthreads();
+    if (hi == 0 && row < N) {
+        grp[(size_t)cloud * N + row] = besti;
+        if (counts) atomicAdd(&hist[besti], 1);
+    }
+    if (counts) {
+        __syncthreads();
+        if (tid < P && hist[tid]) atomicAdd(counts + (size_t)cloud * P + tid, hist[tid]);
+    }
+}
+
+// One workgroup per (group, cloud): (1) the group's member rows as a compact list in row order (512 rows at a time: ballots and a
+// prefix over the 8 waves), (2)
+//   MEAN: the member rows added up -- thread (q, d) adds members q, q + 4, .. of feature d in list order, then (s0 + s1) + (s2 + s3):
+//         a fixed order, the same sums in every run -- and the normalised sum written out (a zero vector for an empty group:
+//         F.normalize's eps);
+//   else: member i of the group written to position start[group] + i of the sorted order: row index, the row itself, and the
+//         group's super-group.
+template <bool MEAN>
+__global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __restrict__ X, const int* __restrict__ grp, int N, int P,
+                                                              float* __restrict__ piv, const int* __restrict__ start,
+                                                              const int* __restrict__ comp, int* __restrict__ order,
+                                                              float* __restrict__ Xs, int* __restrict__ scomp) {
+    __shared__ unsigned short members[16384];
+    __shared__ int wcnt[8];
+    __shared__ float part[4][PREP_D];
+    __shared__ float red[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x, cloud = blockIdx.y;
+    const float* Xc = X + (size_t)cloud * N * PREP_D;
+    const int* gc = grp + (size_t)cloud * N;
+    int cnt = 0;
+    for (int r0 = 0; r0 < N; r0 += 512) {
+        const int r = r0 + tid;
+        const bool in = r < N && gc[r] == p;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+        if (lane == 0) wcnt[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = cnt;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int c = wcnt[v];
+            if (v < wave) off += c;
+            cnt += c;
+        }
+        if (in) members[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
+        __syncthreads();
+    }
+    const int q = tid >> 7, d = tid & 127;
+    if (MEAN) {
+        float acc = 0.f;
+        for (int i = q; i < cnt; i += 32) {                 // 8 rows in flight per thread, added in list order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i + 4 * u < cnt ? Xc[(size_t)members[i + 4 * u] * PREP_D + d] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        part[q][d] = acc;
+        __syncthreads();
+        if (tid < PREP_D) {
+            const float sum = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            float s2 = sum * sum;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+            if (lane == 0) red[wave] = s2;
+            part[0][tid] = sum;
+        }
+        __syncthreads();
+        if (tid < PREP_D) piv[((size_t)cloud * P + p) * PREP_D + tid] = part[0][tid] / fmaxf(sqrtf(red[0] + red[1]), 1.0e-12f);
+    } else {
+        const int pos0 = start[(size_t)cloud * P + p], sg = comp[(size_t)cloud * P + p];
+        for (int i = q; i < cnt; i += 4) {
+            const int row = members[i];
+            Xs[((size_t)cloud * N + pos0 + i) * PREP_D + d] = Xc[(size_t)row * PREP_D + d];
+            if (d == 0) {
+                order[(size_t)cloud * N + pos0 + i] = row;
+                scomp[(size_t)cloud * N + pos0 + i] = sg;
+            }
+        }
+    }
+}
+
+// Per cloud: which means are within merge_angle of each other, the connected components of that graph (super-groups, named by
+// their smallest member), and where every group starts in the order sorted by (super-group, group). One wave; thread p = group p.
+__global__ __launch_bounds__(64) void prep_components_kernel(const float* __restrict__ piv, const int* __restrict__ counts, int P,
+                                                             float cos_merge, int* __restrict__ comp, int* __restrict__ start) {
+    __shared__ float pv[PREP_P * (PREP_D + 1)];
+    __shared__ int cc[PREP_P], cnt[PREP_P];
+    const int p = threadIdx.x, cloud = blockIdx.x;
+    const float* pc = piv + (size_t)cloud * P * PREP_D;
+    for (int i = p; i < P * PREP_D; i += 64) pv[(i >> 7) * (PREP_D + 1) + (i & 127)] = pc[i];
+    cc[p] = p;
+    cnt[p] = p < P ? counts[(size_t)cloud * P + p] : 0;
+    __syncthreads();
+    unsigned long long reach = 0ull;
+    if (p < P)
+        for (int q = 0; q < P; ++q) {
+            float d = 0.f;
+            for (int k = 0; k < PREP_D; ++k) d = fmaf(pv[p * (PREP_D + 1) + k], pv[q * (PREP_D + 1) + k], d);
+            if (d > cos_merge || q == p) reach |= 1ull << q;
+        }
+    // the relation need not be symmetric in floating point only by rounding of d(p, q) vs d(q, p): the sums run in the same
+    // order, so it is. Label propagation: at most P - 1 rounds.
+    for (int round = 0; round < PREP_P; ++round) {
+        int c = cc[p];
+        unsigned long long m = reach;
+        while (m) {
+            const int q = __builtin_ctzll(m);
+            m &= m - 1;
+            c = min(c, cc[q]);
+        }
+        __syncthreads();
+        const bool changed = c != cc[p];
+        cc[p] = c;
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(changed) == 0ull) break;
+    }
+    if (p < P) {
+        const int key = cc[p] * PREP_P + p;
+        int s = 0;
+        for (int q = 0; q < P; ++q)
+            if (cc[q] * PREP_P + q < key) s += cnt[q];
+        comp[(size_t)cloud * P + p] = cc[p];
+        start[(size_t)cloud * P + p] = s;
+    }
+}
+
+// Two references per 32-row tile of the sorted rows (src of the rule: ms_iterate_d128_f16s_kernel's header): the rows of the
+// tile's first super-group and the rest -- a tile inside one super-group: its two halves -- each with the normalised sum of its
+// rows and the smallest dot product of a row with it (1 for an empty group). Tiles past the end of the cloud: zero rows,
+// cos alpha = 1. The last tile of a ragged cloud is filled up with copies of the last row. 128 threads per tile slot.
+__global__ __launch_bounds__(128) void prep_tile_refs_kernel(const float* __restrict__ Xs, const int* __restrict__ scomp, int N,
+                                                             int nref, float* __restrict__ ref, float* __restrict__ cosalpha) {
+    __shared__ float xt[32 * (PREP_D + 1)];
+    __shared__ float m[2][PREP_D];
+    __shared__ float part[4][32];
+    __shared__ float red[2][2];
+    __shared__ int sc[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x, cloud = blockIdx.y;
+    const int ntile = (N + 31) >> 5;
+    const int rho0 = ((t >> 5) * 2) * 32 + (t & 31), rho1 = rho0 + 32;
+    float* r0p = ref + ((size_t)cloud * nref + rho0) * PREP_D;
+    float* r1p = ref + ((size_t)cloud * nref + rho1) * PREP_D;
+    if (t >= ntile) {
+        r0p[tid] = 0.f;
+        r1p[tid] = 0.f;
+        if (tid == 0) { cosalpha[(size_t)cloud * nref + rho0] = 1.f; cosalpha[(size_t)cloud * nref + rho1] = 1.f; }
+        return;
+    }
+    const float* Xc = Xs + (size_t)cloud * N * PREP_D;
+    if (tid < 32) sc[tid] = scomp[(size_t)cloud * N + min(32 * t + tid, N - 1)];
+    for (int r = 0; r < 32; ++r) xt[r * (PREP_D + 1) + tid] = Xc[(size_t)min(32 * t + r, N - 1) * PREP_D + tid];
+    __syncthreads();
+    bool pure = true;
+    for (int r = 1; r < 32; ++r) pure = pure && sc[r] == sc[0];
+    auto in_a = [&](int r) { return pure ? r < 16 : sc[r] == sc[0]; };
+    float sa = 0.f, sb = 0.f;
+    for (int r = 0; r < 32; ++r) {
+        const float v = xt[r * (PREP_D + 1) + tid];
+        if (in_a(r)) sa += v;
+        else sb += v;
+    }
+    float qa = sa * sa, qb = sb * sb;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { qa += __shfl_xor(qa, off, 64); qb += __shfl_xor(qb, off, 64); }
+    if (lane == 0) { red[wave][0] = qa; red[wave][1] = qb; }
+    __syncthreads();
+    const float ma = sa / fmaxf(sqrtf(red[0][0] + red[1][0]), 1.0e-12f);
+    const float mb = sb / fmaxf(sqrtf(red[0][1] + red[1][1]), 1.0e-12f);
+    m[0][tid] = ma;
+    m[1][tid] = mb;
+    r0p[tid] = ma;
+    r1p[tid] = mb;
+    __syncthreads();
+    {   // dot of row r with its own group's reference: 4 threads per row, 32 features each
+        const int r = tid & 31, q = tid >> 5;
+        const float* mm = m[in_a(r) ? 0 : 1];
+        float d = 0.f;
+        for (int k = 32 * q; k < 32 * q + 32; ++k) d = fmaf(xt[r * (PREP_D + 1) + k], mm[k], d);
+        part[q][r] = d;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        float da = in_a(tid) ? d : 1.f, db = in_a(tid) ? 1.f : d;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { da = fminf(da, __shfl_xor(da, off, 64)); db = fminf(db, __shfl_xor(db, off, 64)); }
+        if (tid == 0) { cosalpha[(size_t)cloud * nref + rho0] = da; cosalpha[(size_t)cloud * nref + rho1] = db; }
+    }
+}
+
+// out[order[i]] = in[i] (rows of 128 floats): the result of the block-sparse pass back in the caller's row order
+__global__ __launch_bounds__(256) void unsort_rows_kernel(const float* __restrict__ in, const int* __restrict__ order,
+                                                          float* __restrict__ out, size_t rows, int N) {
+    const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= rows) return;
+    const size_t cloud = i / N;
+    const int dst = order[i];
+    *(f32x4*)(out + (cloud * N + dst) * PREP_D + 4 * (threadIdx.x & 31)) = *(const f32x4*)(in + i * PREP_D + 4 * (threadIdx.x & 31));
+}
+
+struct PrepCarve {
+    int *picks, *grp, *counts, *comp, *start, *scomp;
+    float *picked, *piv;
+    size_t bytes;
+};
+static PrepCarve prep_carve(void* ws, int B, int N, int P) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    uint8_t* b = (uint8_t*)ws;
+    PrepCarve c;
+    size_t o = 0;
+    c.picks = (int*)(b + o); o += up((size_t)B * P * sizeof(int));
+    c.counts = (int*)(b + o); o += up((size_t)B * P * sizeof(int));
+    c.comp = (int*)(b + o); o += up((size_t)B * P * sizeof(int));
+    c.start = (int*)(b + o); o += up((size_t)B * P * sizeof(int));
+    c.grp = (int*)(b + o); o += up((size_t)B * N * sizeof(int));
+    c.scomp = (int*)(b + o); o += up((size_t)B * N * sizeof(int));
+    c.picked = (float*)(b + o); o += up((size_t)B * P * PREP_D * sizeof(float));
+    c.piv = (float*)(b + o); o += up((size_t)B * P * PREP_D * sizeof(float));
+    c.bytes = o;
+    return c;
+}
+
+}  // namespace
+
+extern "C" size_t sed_ms_sparse_prepare_workspace_bytes(int B, int N, int P) {
+    if (B <= 0 || N <= 0 || P <= 0) return 0;
+    return prep_carve(nullptr, B, N, P).bytes;
+}
+
+// X [B,N,128] unit rows -> order [B,N] (sorted position -> row), Xs [B,N,128] = the rows in that order, tile_ref [B,nref,128] and
+// tile_cosalpha [B,nref] as sed_ms_iterate_bounds_f16_f32 takes them (nref = sed_ms_iterate_bounds_f16_refs(N)). P <= 64 pivots
+// among every stride-th row (at most 4096 candidates), merge_angle in radians.
+extern "C" int sed_ms_sparse_prepare_f32(int B, int N, int d, int P, int stride, float merge_angle, const float* X, int* order,
+                                         float* Xs, float* tile_ref, float* tile_cosalpha, void* workspace,
+                                         size_t workspace_bytes, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || P <= 0 || stride <= 0 || !X || !order || !Xs || !tile_ref || !tile_cosalpha || !workspace ||
+        !(merge_angle >= 0.f))
+        return SED_EINVAL;
+    if (d != PREP_D || P > PREP_P || N > 16384 || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride)
+        return SED_EUNSUPPORTED;
+    const PrepCarve c = prep_carve(workspace, B, N, P);
+    if (workspace_bytes < c.bytes) return SED_EINVAL;
+    const int nst = (N + 31) / 32, nref = 2 * ((nst + 31) / 32) * 32;
+    hipError_t e = hipMemsetAsync(c.counts, 0, (size_t)B * P * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    fps_pivots_kernel<<<B, 1024, 0, stream>>>(X, N, stride, P, c.picks, c.picked);
+    const dim3 ga((N + 127) / 128, B), gw(P, B);
+    prep_assign_kernel<<<ga, 256, 0, stream>>>(X, c.picked, N, P, c.grp, nullptr);
+    prep_group_walk_kernel<true><<<gw, 512, 0, stream>>>(X, c.grp, N, P, c.piv, nullptr, nullptr, nullptr, nullptr, nullptr);
+    prep_assign_kernel<<<ga, 256, 0, stream>>>(X, c.piv, N, P, c.grp, c.counts);
+    prep_components_kernel<<<B, 64, 0, stream>>>(c.piv, c.counts, P, cosf(merge_angle), c.comp, c.start);
+    prep_group_walk_kernel<false><<<gw, 512, 0, stream>>>(X, c.grp, N, P, nullptr, c.start, c.comp, order, Xs, c.scomp);
+    prep_tile_refs_kernel<<<dim3(nref / 2, B), 128, 0, stream>>>(Xs, c.scomp, N, nref, tile_ref, tile_cosalpha);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" int sed_unsort_rows_f32(int B, int N, int d, const float* in, const int* order, float* out, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !in || !order || !out) return SED_EINVAL;
+    if (d != PREP_D) return SED_EUNSUPPORTED;
+    const size_t rows = (size_t)B * N;
+    unsort_rows_kernel<<<(unsigned)((rows + 7) / 8), 256, 0, stream>>>(in, order, out, rows, N);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -296,93 +296,36 @@ def ms_near_fraction(X, bw, skip_below=-30.0, rows=64, keys=512):
     return torch.where(torch.isfinite(dist).all(2).all(1), frac, torch.ones_like(frac))     # NaN / inf rows: dense path
 
 
-def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
-    """Row order that makes 32-row blocks cluster-pure. Every row joins its nearest of `n_pivots` farthest-point pivot
-    rows (largest dot product on the unit sphere); pivots closer than `merge_angle` (single linkage) form a super-group, and
-    rows are stable-sorted by (super-group, pivot) so that the pivot groups of one cluster are adjacent.
-    -> (order [B,N] int64, pivots [B,P,D], dots of the SORTED rows with all pivots [B,N,P], super-group of the sorted
-    rows [B,N])."""
-    B, N, D = X.shape
-    P = min(n_pivots, N)
-    # farthest-point pivots (greedy k-centre on the sphere): every cluster gets at least one pivot as long as there are
-    # no more clusters than pivots, so no row is left far from its pivot (a far row would need every block)
-    # (picked among every `stride`-th row: the greedy loop is 64 dependent passes over the rows it looks at, and a quarter of
-    # a 10 000-point cloud still holds a dozen rows of a cluster of 0.5 % of the points)
-    stride = 4 if N >= 4096 else 1
-    picked = torch.empty((B, P, D), dtype=torch.float32, device=X.device)
-    if D == 128 and X.is_cuda and (N + stride - 1) // stride <= 4096:
-        picks = torch.empty((B, P), dtype=torch.int32, device=X.device)
-        check(lib.sed_fps_pivots_f32(B, N, D, stride, P, ptr(X), ptr(picks), ptr(picked), stream()), "fps_pivots")
-    else:
-        Xf = X[:, ::stride].contiguous() if stride > 1 else X
-        bidx = torch.arange(B, device=X.device)
-        pick = torch.zeros((B,), dtype=torch.long, device=X.device)
-        closest = None
-        for j in range(P):
-            picked[:, j] = Xf[bidx, pick]
-            dj = torch.bmm(Xf, picked[:, j].unsqueeze(2)).squeeze(2)
-            closest = dj if closest is None else torch.maximum(closest, dj)
-            pick = closest.argmin(1)
-    dots = torch.bmm(X, picked.transpose(1, 2))
-    # one k-means step: reference directions = normalised means of the pivot groups (any unit vectors are valid
-    # references; the mean sits in the middle of its group, which tightens every angular bound by about a third)
-    grp = dots.argmax(2)
-    # (group sums as a one-hot matrix product, not scatter_add_: float atomics add in a different order every run, the means
-    # change in their last bits, a row near two pivots changes group, the row order changes -- and with it the summation order
-    # of the whole block-sparse pass: results were not bit-reproducible from run to run)
-    onehot = torch.nn.functional.one_hot(grp, P).to(X.dtype)                  # [B,N,P]
-    piv = torch.bmm(onehot.transpose(1, 2), X)
-    piv = torch.nn.functional.normalize(piv, dim=2).contiguous()
-    dots = torch.bmm(X, piv.transpose(1, 2))
-    grp = dots.argmax(2)
-    reach = (torch.bmm(piv, piv.transpose(1, 2)) > float(torch.cos(torch.tensor(merge_angle)))).float()
-    for _ in range(6):                                                        # transitive closure of a 64-node graph
-        reach = (torch.bmm(reach, reach) > 0).float()
-    comp = torch.where(reach > 0, torch.arange(P, device=X.device).view(1, 1, P), P).min(2)[0]     # [B,P] min member
-    key = torch.gather(comp, 1, grp) * P + grp
-    skey, order = torch.sort(key, dim=1, stable=True)
-    return order, piv, torch.gather(dots, 1, order.unsqueeze(-1).expand(B, N, P)), skey // P
-
-
-def ms_sparse_prepare(X, n_pivots=64):
-    """Sorted rows + the geometric side tables of the block-sparse kernel (functions of X alone): per 32-row tile two
-    normalised group means and the smallest dot product of a row of each group with its mean. -> dict."""
+def ms_sparse_prepare(X, n_pivots=64, merge_angle=0.6):
+    """Sorted rows + the geometric side tables of the block-sparse kernel (functions of X alone), one C call
+    (sed_ms_sparse_prepare_f32, ms_sparse_prep.hip): rows join the nearest of `n_pivots` farthest-point pivot rows, the pivot groups
+    are replaced by their normalised means and the rows re-assigned, means closer than `merge_angle` (single linkage) form a
+    super-group, rows are stable-sorted by (super-group, group) so that 32-row tiles are cluster-pure, and every tile gets two
+    normalised group means with the smallest dot product of a row of each group with its mean.
+    -> dict(order [B,N] int32: sorted position -> row, Xs [B,N,D], ref [B,nref,D], cosalpha [B,nref])."""
     B, N, D = X.shape
     if N > 16384 or D != 128:
         raise RuntimeError("block-sparse mean-shift schedule: d = 128 and N <= 16384 only")
-    order, piv, sdots, comp = ms_pivot_order(X, n_pivots)
-    gidx = order.unsqueeze(-1).expand(B, N, D)
-    Xs = torch.gather(X, 1, gidx).contiguous()
-    prep = {"gidx": gidx, "Xs": Xs}
-    ntile = (N + 31) // 32
-    pad = ntile * 32 - N
-    if True:
-        # two references per tile: the rows of the tile's first super-group and the rest (a tile inside one cluster: its two
-        # halves), so that the tile at the border between two clusters is covered by two narrow caps instead of a wide one
-        if pad:                                                               # pad with copies of the last row
-            Xs_p = torch.cat([Xs, Xs[:, -1:].expand(B, pad, D)], 1)
-            comp = torch.cat([comp, comp[:, -1:].expand(B, pad)], 1)
-        else:
-            Xs_p = Xs
-        Xt = Xs_p.view(B, ntile, 32, D)
-        ct = comp.view(B, ntile, 32)
-        first = ct == ct[:, :, :1]
-        pure = first.all(2, keepdim=True)
-        half = (torch.arange(32, device=X.device) < 16).view(1, 1, 32)
-        ga = torch.where(pure, half, first)                                   # group of reference 0; reference 1: the rest
-        nref = lib.sed_ms_iterate_bounds_f16_refs(N)
-        ref = torch.zeros((B, nref, D), dtype=torch.float32, device=X.device)
-        cosalpha = torch.ones((B, nref), dtype=torch.float32, device=X.device)
-        t = torch.arange(ntile, device=X.device)
-        for w, g in enumerate((ga, ~ga)):
-            gf = g.unsqueeze(-1).float()
-            m = torch.nn.functional.normalize((Xt * gf).sum(2), dim=2)
-            dots = (Xt * m.unsqueeze(2)).sum(3)
-            rho = ((t // 32) * 2 + w) * 32 + t % 32
-            ref[:, rho] = m
-            cosalpha[:, rho] = torch.where(g, dots, torch.ones_like(dots)).min(2)[0]
-        prep.update(ref=ref, cosalpha=cosalpha)
-    return prep
+    P = min(n_pivots, 64, N)
+    # (pivots picked among every `stride`-th row: the greedy loop is P dependent passes over the rows it looks at, and a
+    # quarter of a 10 000-point cloud still holds a dozen rows of a cluster of 0.5 % of the points)
+    stride = 4 if N >= 4096 else 1
+    nref = lib.sed_ms_iterate_bounds_f16_refs(N)
+    order = torch.empty((B, N), dtype=torch.int32, device=X.device)
+    Xs = torch.empty_like(X)
+    ref = torch.empty((B, nref, D), dtype=torch.float32, device=X.device)
+    cosalpha = torch.empty((B, nref), dtype=torch.float32, device=X.device)
+    nws = lib.sed_ms_sparse_prepare_workspace_bytes(B, N, P)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=X.device)
+    check(lib.sed_ms_sparse_prepare_f32(B, N, D, P, stride, float(merge_angle), ptr(X), ptr(order), ptr(Xs), ptr(ref),
+                                        ptr(cosalpha), ptr(ws), nws, stream()), "ms_sparse_prepare")
+    return {"order": order, "Xs": Xs, "ref": ref, "cosalpha": cosalpha}
+
+
+def ms_pivot_order(X, n_pivots=64, merge_angle=0.6):
+    """-> (order, Xs, ref, cosalpha) of ms_sparse_prepare"""
+    prep = ms_sparse_prepare(X, n_pivots, merge_angle)
+    return prep["order"], prep["Xs"], prep["ref"], prep["cosalpha"]
 
 
 def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
@@ -404,7 +347,9 @@ def ms_sparse_run(prep, bw, iters, skip_below=-30.0, margin=2e-3, stats=None):
     if TIMERS is not None:
         ev1.record()
         TIMERS.append(("ms_iterate_sparse", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters)}))
-    return torch.empty_like(outs).scatter_(1, prep["gidx"], outs)
+    out = torch.empty_like(outs)
+    check(lib.sed_unsort_rows_f32(B, N, D, ptr(outs), ptr(prep["order"]), ptr(out), stream()), "unsort_rows")
+    return out
 
 
 def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, margin=2e-3, stats=None):

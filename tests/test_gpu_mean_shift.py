@@ -444,6 +444,58 @@ def test_every_schedule_is_bit_reproducible(T):
         assert all(T.equal(a, b) for a, b in zip(o0, ops.ms_pivot_order(X)))
 
 
+def test_sparse_preparation_kernels_keep_the_invariants_the_skipping_rule_needs(T):
+    """sed_ms_sparse_prepare_f32 (pivots, k-means step, super-groups, stable sort, tile references -- HIP kernels, no library
+    calls): the order is a permutation, Xs are the rows in that order, every reference is a unit vector (or zero for an empty
+    group), and EVERY row lies inside the cap of one of its tile's two references (row . ref >= cos alpha): that is all the
+    block-sparse kernel's bound relies on. On planted clusters nearly all tiles come out cluster-pure. Ragged N, N below the
+    pivot-stride switch, and the argument checks."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import lib, ptr, stream
+    for N, ncl in ((10000, 12), (9973, 17), (2047, 5), (1024, 3)):
+        embs = [synth.clustered_embedding(N=N, d=128, n_clusters=ncl + c, sigma=0.02, seed=900 + c) for c in range(3)]
+        X = dev(T, np.stack([e[0] for e in embs]))
+        lab = np.stack([e[1] for e in embs])
+        prep = ops.ms_sparse_prepare(X)
+        order = prep["order"].long()
+        assert (T.sort(order, 1)[0] == T.arange(N, device="cuda")[None]).all()
+        assert T.equal(prep["Xs"], T.gather(X, 1, order.unsqueeze(-1).expand(-1, -1, 128)))
+        nt = (N + 31) // 32
+        t = T.arange(nt, device="cuda")
+        ref, ca = prep["ref"], prep["cosalpha"]
+        assert ref.shape[1] == lib.sed_ms_iterate_bounds_f16_refs(N)
+        rows = T.cat([prep["Xs"], prep["Xs"][:, -1:].expand(-1, nt * 32 - N, -1)], 1).view(3, nt, 32, 128)
+        inside = T.zeros((3, nt, 32), dtype=T.bool, device="cuda")
+        for w in range(2):
+            rho = ((t // 32) * 2 + w) * 32 + t % 32
+            m, c = ref[:, rho], ca[:, rho]                                  # [3,nt,128], [3,nt]
+            nrm = m.norm(dim=2)
+            assert (((nrm - 1).abs() < 1e-5) | (nrm == 0)).all()
+            inside |= ((rows * m.unsqueeze(2)).sum(3) >= c.unsqueeze(2) - 1e-6) & (nrm > 0).unsqueeze(2)
+        assert inside.all()
+        used = T.zeros(ref.shape[1], dtype=T.bool, device="cuda")
+        for w in range(2):
+            used[((t // 32) * 2 + w) * 32 + t % 32] = True
+        assert (ref[:, ~used] == 0).all() and (ca[:, ~used] == 1).all()
+        sl = np.take_along_axis(lab, order.cpu().numpy(), 1)
+        sl = np.concatenate([sl, np.repeat(sl[:, -1:], nt * 32 - N, 1)], 1).reshape(3, nt, 32)
+        pure = (sl == sl[:, :, :1]).all(2).mean()
+        assert pure > 0.9 - 32.0 * (ncl + 2) / N, (N, pure)                 # at most about one mixed tile per cluster border
+        again = ops.ms_sparse_prepare(X)
+        assert all(T.equal(prep[k], again[k]) for k in prep)
+    X = dev(T, synth.clustered_embedding(N=1024, d=128, n_clusters=3, sigma=0.02, seed=1)[0][None])
+    o, xs = T.empty((1, 1024), dtype=T.int32, device="cuda"), T.empty_like(X)
+    nref = lib.sed_ms_iterate_bounds_f16_refs(1024)
+    r, c = T.empty((1, nref, 128), device="cuda"), T.empty((1, nref), device="cuda")
+    nws = lib.sed_ms_sparse_prepare_workspace_bytes(1, 1024, 64)
+    ws = T.empty((nws,), dtype=T.uint8, device="cuda")
+    call = lambda d, P, stride, nb: lib.sed_ms_sparse_prepare_f32(1, 1024, d, P, stride, 0.6, ptr(X), ptr(o), ptr(xs), ptr(r), ptr(c),
+                                                                  ptr(ws), nb, stream())
+    assert call(128, 64, 1, nws) == 0
+    assert call(64, 64, 1, nws) == -2 and call(128, 65, 1, nws) == -2 and call(128, 64, 32, nws) == -2      # 32 candidates < 64 pivots
+    assert call(128, 64, 1, nws - 1) == -1 and call(128, 64, 0, nws) == -1
+
+
 def test_nan_cloud_does_not_derail_the_sparse_path(T):
     """A cloud with NaN rows next to clustered clouds: the density probe sends it to the dense path ("auto"); forced through
     the sparse path the pivot kernel stays inside the cloud (NaN never compares smaller), the split kernel flags it and the

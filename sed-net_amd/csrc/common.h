@@ -87,6 +87,12 @@ __device__ __forceinline__ float sed_vmax(float a, float b) {
     return r;
 }
 
+// The same for an operand that comes STRAIGHT out of an MFMA accumulator: the hazard recogniser does not count an inline-asm
+// read as a VALU read of the matrix pipe's result, so sed_vmax on a fresh accumulator register can issue before the MFMA has
+// written it (seen in edgeconv_x3_kernel: the first rows of a tile kept stale values). v_med3_f32 with +inf as third operand is
+// max(a, b) as one instruction the compiler knows.
+__device__ __forceinline__ float sed_vmax_acc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+
 static inline int sed_pad_dim(int d) {      // feature width the MFMA kernels are instantiated for
     if (d <= 32) return 32;
     if (d <= 64) return 64;

@@ -244,6 +244,179 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float* __restric
     }
 }
 
+// Inference form of the 64-channel layers (round 3): the X3 arithmetic of edgeconv_kernel above -- bit-identical outputs -- with
+// the per-neighbour VALU work cut from ~420 to ~260 instructions per 48 MFMAs (the kernel was VALU-bound at 0.18 of the matrix
+// pipe): the sign of gamma is folded into the weight images (w' = sgn_o w: products and sums are sign-symmetric, so
+// max_j (sgn y) needs no multiply and the statistics are restored by one multiply per wave); rows past the end of the cloud are
+// made exact zeros once (their neighbour is their own clamped centre, their centre term is masked after it is computed) instead
+// of being masked in every neighbour's statistics; the first MFMA of a neighbour takes the centre term as its C operand
+// instead of a copied accumulator; max is a bare v_max_f32.
+__global__ __launch_bounds__(256, 2) void edgeconv_x3_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ idx, int k,
+                                                             const float* __restrict__ W1t, const float* __restrict__ W2t, int Cout,
+                                                             const float* __restrict__ sgn, float* __restrict__ ysel,
+                                                             double* __restrict__ part, int N) {
+    constexpr int CH = 32, C = 64;
+    constexpr int LDWB = C + 8;                  // bf16 image row stride in halves (144 B)
+    constexpr int WPL = 64 * LDWB;               // one bf16 plane of one weight half
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* w1b = (__bf16*)smem;                 // [3][64][LDWB]
+    __bf16* w2b = w1b + 3 * WPL;
+    double* red = (double*)((uint8_t*)smem + (size_t)2 * 3 * WPL * sizeof(__bf16));      // [4 waves][2 tiles][2]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int nbx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * nbx + blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int cloud = wgid / nbx, bxi = wgid - cloud * nbx;
+    const int slab = blockIdx.z, o0 = slab * 64;
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, o = i & 63;
+        const float sg = sgn[o0 + o];
+        const float* src[2] = {W1t, W2t};
+        __bf16* dst[2] = {w1b, w2b};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float v = sg * src[h][(size_t)c * Cout + o0 + o];
+            const __bf16 p1 = (__bf16)v;
+            const float r1 = v - (float)p1;
+            const __bf16 p2 = (__bf16)r1;
+            dst[h][o * LDWB + c] = p1;
+            dst[h][WPL + o * LDWB + c] = p2;
+            dst[h][2 * WPL + o * LDWB + c] = (__bf16)(r1 - (float)p2);
+        }
+    }
+    __syncthreads();
+    // acc = init + v W'  (this lane's 32 channels = k-steps 8 s8 .. 8 s8 + 7 of lane half hi). The three weight planes of step
+    // (s8, t) are read from LDS one step AHEAD of the six MFMAs that use them (left to itself hipcc puts every ds_read right in
+    // front of its MFMA with an lgkmcnt(0) between them: 20 exposed LDS latencies per neighbour).
+    auto mma3 = [&](const float (&v)[CH], const __bf16* wb, const f32x16 (&init)[2], f32x16 (&acc)[2]) {
+        const __bf16* wl = wb + li * LDWB + hi * CH;
+        bf16x8 bq[2][3];
+        auto rd = [&](int g, bf16x8 (&b)[3]) {            // g = 2 s8 + t
+            const __bf16* wp = wl + 32 * (g & 1) * LDWB + 8 * (g >> 1);
+            b[0] = *(const bf16x8*)wp;
+            b[1] = *(const bf16x8*)(wp + WPL);
+            b[2] = *(const bf16x8*)(wp + 2 * WPL);
+        };
+        rd(0, bq[0]);
+        bf16x8 a1, a2, a3;
+#pragma unroll
+        for (int g = 0; g < 2 * (CH / 8); ++g) {
+            const int s8 = g >> 1, t = g & 1;
+            if (g + 1 < 2 * (CH / 8)) rd(g + 1, bq[(g + 1) & 1]);
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float x0 = v[8 * s8 + i];
+                    const __bf16 p1 = (__bf16)x0;
+                    const float r1 = x0 - (float)p1;
+                    const __bf16 p2 = (__bf16)r1;
+                    a1[i] = p1; a2[i] = p2; a3[i] = (__bf16)(r1 - (float)p2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 b1 = bq[g & 1][0], b2 = bq[g & 1][1], b3 = bq[g & 1][2];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, s8 == 0 ? init[t] : acc[t], 0, 0, 0);      // smallest terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+        }
+    };
+
+    const int p0 = bxi * 128 + wave * 32;
+    const int p = p0 + li;
+    const bool valid = p < N;
+    const int pc = valid ? p : N - 1;
+    const float* xb = x + (size_t)cloud * N * ldx;
+    const int* ib = idx + ((size_t)cloud * N + pc) * k;
+    auto load_row = [&](int row, float (&dst)[CH]) {
+        const float* src = xb + (size_t)row * ldx + hi * CH;
+#pragma unroll
+        for (int s = 0; s < CH; s += 4) {
+            const f32x4 v = *(const f32x4*)(src + s);
+            dst[s] = v[0]; dst[s + 1] = v[1]; dst[s + 2] = v[2]; dst[s + 3] = v[3];
+        }
+    };
+    float xc[CH];
+    load_row(pc, xc);
+    f32x16 zero[2], base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[t][r] = 0.f;
+    mma3(xc, w2b, zero, base);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (p0 + mfma_row(r, hi) >= N) { base[0][r] = 0.f; base[1][r] = 0.f; }       // rows past the end: y = 0 for every neighbour
+
+    f32x16 sel[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sel[t][r] = -3.0e38f;
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+
+    // neighbour rows are fetched one neighbour ahead, their indices two ahead: the row loads of neighbour j + 1 then start from
+    // an index that is already in a register instead of waiting for its load at the top of every iteration
+    float nxt[CH];
+    load_row(valid ? ib[0] : pc, nxt);
+    int inext = k > 1 ? ib[1] : 0;
+    for (int j = 0; j < k; ++j) {
+        float diff[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) diff[s] = nxt[s] - xc[s];         // feature - x   (PointNet.py:170)
+        if (j + 1 < k) load_row(valid ? inext : pc, nxt);
+        if (j + 2 < k) inext = ib[j + 2];
+        f32x16 acc[2];
+        // (the weight operands are re-read from LDS for every neighbour: hoisted out of the loop they are 96 registers, and the
+        // kernel -- 256 per wave at two waves per SIMD -- then spills 13 x 16 bytes per neighbour onto the MFMAs' critical path)
+        int woff = 0;
+        asm volatile("" : "+v"(woff));
+        mma3(diff, w1b + woff, base, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float ps = 0.f, pq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r];
+                sel[t][r] = sed_vmax_acc(sel[t][r], v);
+                ps += v;
+                pq = fmaf(v, v, pq);
+            }
+            s1[t] += (double)ps;
+            s2[t] += (double)pq;
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float sg = sgn[o0 + 32 * t + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = p0 + mfma_row(r, hi);
+            if (row < N) ysel[((size_t)cloud * N + row) * Cout + o0 + 32 * t + li] = sg * sel[t][r];
+        }
+        s1[t] *= (double)sg;                                  // sum of sgn y = sgn sum of y, exactly
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1[t] += __shfl_xor(s1[t], off, 64);
+            s2[t] += __shfl_xor(s2[t], off, 64);
+        }
+        if (lane == 0) { red[(wave * 2 + t) * 2] = s1[t]; red[(wave * 2 + t) * 2 + 1] = s2[t]; }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int t = tid >> 1, which = tid & 1;
+        double a = 0.0;
+        for (int w = 0; w < 4; ++w) a += red[(w * 2 + t) * 2 + which];
+        const int ntile = Cout / 32;
+        part[(((size_t)cloud * gridDim.x + bxi) * ntile + slab * 2 + t) * 2 + which] = a;
+    }
+}
+
 // mean / rstd per (cloud, group) from per-block, per-32-channel-tile partial sums (fixed order, fp64)
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
                                    float eps, float* __restrict__ stats /*[B][G][2]*/) {
@@ -303,8 +476,7 @@ static int edgeconv_fwd(int B, int N, int C, int Cout, int k, int G, const float
             edgeconv_kernel<32, true><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, jsel);
         else if (x3) {
             const size_t sm3 = (size_t)2 * 3 * 64 * (64 + 8) * sizeof(__bf16) + 16 * sizeof(double) + 64;
-            edgeconv_kernel<32, false, false, true><<<grid, block, sm3, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N,
-                                                                                  nullptr);
+            edgeconv_x3_kernel<<<grid, block, sm3, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N);
         } else
             edgeconv_kernel<32, false><<<grid, block, sm, stream>>>(x, ldx, idx, k, W1t, W2t, Cout, sgn, ysel, part, N, nullptr);
     } else {

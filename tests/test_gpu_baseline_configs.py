@@ -221,11 +221,12 @@ def test_config2_batch64_trained_network_no_injection(T, golden, capsys):
     """BASELINE configs[2] as bench.py runs it since round 3: 64 x 10 000 points through the whole HIP path with TRAINED weights
     and nothing injected -- the network's own embedding is clustered, its own argmax votes the segment types, the fits run on
     what comes out. Clouds 0 and 1 of the batch are the two clouds of f_10k.npz: their labels / types out of the BATCHED pipeline
-    agree with the reference's outputs like the single-cloud flow does (test_config0); every cloud has real structure."""
-    from conftest import label_agreement, seg_iou_delta
+    agree with the reference's outputs like the single-cloud flow does (test_config0) -- up to as many labels as the reference's
+    own output changes by under 1e-5 of input noise; every cloud has real structure."""
+    from conftest import label_agreement, label_budget, seg_iou_delta
     from sednet_hip import synth
     from sednet_hip.pipeline import SegmentationPipeline
-    g = golden("f_10k")
+    g, unstable = golden("f_10k"), golden("f_10k_unstable")
     B, N, k = 64, 10000, 20
     x, labels, types = synth.batch_clouds(B, N, seed0=1234)
     pipe = SegmentationPipeline(build(T, k, "type"), build(T, k, "inst"), quantile=0.015, iterations=50)
@@ -242,7 +243,8 @@ def test_config2_batch64_trained_network_no_injection(T, golden, capsys):
         d_iou, iou_dev, iou_ref = seg_iou_delta(got[b], g[tag + "labels"], g[tag + "gt_labels"])
         rep.append(f"cloud {b}: types exact {1 - bad_t.mean():.5f}, labels exact {a['rate']:.5f} ({a['n_got']} / {a['n_ref']}), "
                    f"seg-IoU vs ground truth {iou_dev:.5f} (reference {iou_ref:.5f})")
-        assert a["n_got"] == a["n_ref"] and a["rate"] >= 0.999 and a["undecided"].size == 0 and abs(d_iou) <= 1e-3, (a, d_iou)
+        budget = label_budget(unstable, tag)                              # (the reference's own response to 1e-5 of input noise)
+        assert a["n_got"] == a["n_ref"] and a["mismatches"].size <= budget and abs(d_iou) <= 1e-3, (a, d_iou, budget)
     # against the synthetic ground truth (what the few-hundred-step network has learned; reported, loosely bounded)
     gt_rate = np.mean([label_agreement(got[b], labels[b])["rate"] for b in range(8)])
     ty_acc = float((ty[:8] == types[:8]).mean())
@@ -252,9 +254,11 @@ def test_config2_batch64_trained_network_no_injection(T, golden, capsys):
               f"(median {int(np.median(ncl))}); vs ground truth (8 clouds): label match {gt_rate:.3f}, type accuracy {ty_acc:.3f}; "
               f"fitted segments {int(valid.sum())}, guard retries {int((np.asarray(out['passes']) > 1).sum())}")
     assert gt_rate > 0.3 and ty_acc > 0.5 and valid.sum() >= 4 * B
-    one = pipe(T.from_numpy(x[1:2]).cuda())                                 # same cloud alone: same partition
+    # same cloud alone (one cloud per call runs the dense schedule, the batch the block-sparse one: two evaluation orders): the same
+    # partition up to the same budget
+    one = pipe(T.from_numpy(x[1:2]).cuda())
     a1 = label_agreement(one["labels"][0].cpu().numpy(), got[1])
-    assert a1["rate"] >= 0.999 and a1["n_got"] == a1["n_ref"], a1
+    assert a1["mismatches"].size <= budget and a1["n_got"] == a1["n_ref"], a1
 
 
 def test_config4_bf16_training_step_at_full_size():

@@ -176,7 +176,7 @@ def test_driver_at_contract_size_against_the_reference(tmp_path, golden):
     files, one with the "module." prefix -- on bench clouds 0 and 1: the three output files per cloud, and their contents against
     the REFERENCE's outputs for the same clouds (f_10k.npz: types from the type checkpoint, instance labels from the instance
     checkpoint through guard_mean_shift)."""
-    from conftest import label_agreement
+    from conftest import label_agreement, label_budget
     import generate_predictions as gp
     g = golden("f_10k")
     cfg = _write_trained_checkpoints(tmp_path)
@@ -193,7 +193,7 @@ def test_driver_at_contract_size_against_the_reference(tmp_path, golden):
         bad = types != g[tag + "types"]
         assert bad.mean() < 2e-3 and (g[tag + "logp_margin"].astype(np.float32)[bad] < 2e-3).all()
         a = label_agreement(inst, g[tag + "labels"], g[tag + "label_margin"].astype(np.float32), tie=5e-3)
-        assert a["n_got"] == a["n_ref"] and a["rate"] >= 0.999 and a["undecided"].size == 0, a
+        assert a["n_got"] == a["n_ref"] and a["mismatches"].size <= label_budget(golden("f_10k_unstable"), tag), a
 
 
 def test_tta_at_contract_size_matches_oracle(tmp_path):
@@ -235,7 +235,7 @@ def test_driver_default_flow_with_hpnet_at_contract_size(tmp_path, golden):
     are compared with the HPNet-free reference labels only statistically -- same ballpark of clusters, most points in agreeing
     segments -- and the run is reproducible under a fixed torch seed."""
     import torch
-    from conftest import label_agreement
+    from conftest import label_agreement, label_budget
     import generate_predictions as gp
     g = golden("f_10k")
     cfg = _write_trained_checkpoints(tmp_path)

@@ -1041,6 +1041,30 @@ constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a
 // when a query has moved), walked in alternating direction; what changes against the round-2 kernel: small workgroups (NW = 2
 // waves = 128 queries, two per CU) whose waves ALL compute every listed stage (no per-wave skipping inside the list: a skipped
 // block saved its MFMAs but left the pipeline in pieces -- 0.35 of the matrix roof against the dense pipeline's 0.56).
+// Work queue of the persistent block-sparse kernels. sched (ints): [0 .. 2] heads of natural-order queues (counting launch; item_list == NULL),
+// [8 .. 15] / [16 .. 23] heads of the per-XCD queues (iteration launch / its (h, l) redo), [24 .. 31] start and [32 .. 39] length of
+// XCD x's queue inside item_list. A workgroup takes the next item of ITS XCD's queue -- whole clouds, heaviest first, a cloud's
+// items longest first: the workgroups of an XCD work on one or two clouds at a time and their stage images stay in that XCD's
+// L2 (with one global length-sorted list every XCD streamed every cloud: 3.4 TB/s of L2 misses, 20 x the dense kernel's) -- and
+// when that queue is empty, the next item of the following XCDs' queues. An item = (cloud << 8) | block of query rows.
+constexpr int MS_SCHED_INTS = 64;
+__device__ __forceinline__ int ms_next_item(int* __restrict__ sched, const int* __restrict__ item_list, int head0, int nitems, int nbx) {
+    if (item_list == nullptr) {
+        const int j = atomicAdd(sched + head0, 1);          // natural order: head0 = the launch's own counter (0, 1, 2)
+        return j >= nitems ? -1 : ((j / nbx) << 8) | (j % nbx);
+    }
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;          // HW_REG_XCC_ID[3:0]
+    for (int s = 0; s < 8; ++s) {
+        const int x = (xcc + s) & 7;
+        const int len = sched[32 + x];
+        if (len > 0 && __hip_atomic_load(sched + head0 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len) {
+            const int j = atomicAdd(sched + head0 + x, 1);
+            if (j < len) return item_list[sched[24 + x] + j];
+        }
+    }
+    return -1;
+}
+
 constexpr int F16X_NBUF = 3;
 template <int NW, bool PL = true>
 __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
@@ -1048,7 +1072,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
     unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
-    int* __restrict__ queue, int* __restrict__ item_stages) {
+    int* __restrict__ sched, int head0, int* __restrict__ item_stages) {
     constexpr int NT = 4;
     constexpr int MAXW = F16S_MAXW, QB = 64 * NW;         // query rows per workgroup
     constexpr int REFB = 9216;                            // the first 9 DMA pieces of an image hold its 8704-byte head plane
@@ -1078,10 +1102,7 @@ __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
     const int nbx = (N + QB - 1) / QB;
     for (;;) {
     __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
-    if (tid == 0) {
-        const int j = atomicAdd(queue, 1);
-        item_sh = j >= nitems ? -1 : item_list ? item_list[j] : ((j / nbx) << 8) | (j % nbx);
-    }
+    if (tid == 0) item_sh = ms_next_item(sched, item_list, head0, nitems, nbx);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(item_sh);
     if (item < 0) break;
@@ -1618,7 +1639,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
     unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
-    int* __restrict__ queue, int* __restrict__ item_stages) {
+    int* __restrict__ sched, int head0, int* __restrict__ item_stages) {
     using L = StageLayout<32>;
     constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
@@ -1638,10 +1659,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const int nbx = (N + 255) >> 8;
     for (;;) {
     __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
-    if (tid == 0) {
-        const int j = atomicAdd(queue, 1);
-        item_sh = j >= nitems ? -1 : item_list ? item_list[j] : ((j / nbx) << 8) | (j % nbx);
-    }
+    if (tid == 0) item_sh = ms_next_item(sched, item_list, head0, nitems, nbx);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(item_sh);
     if (item < 0) break;
@@ -2186,51 +2204,54 @@ int ms_f16_chunked_launch(int B, int N, int d, int S, int iters, const float* bw
 size_t ms_f16_sparse_workspace_bytes(int B, int N) {
     const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
     return f16_blob_bytes_4(B, N) + f16_blob_bytes_4(B, nref) + 3 * f16_flag_bytes(B) +
-           (size_t)(64 + 2 * (size_t)B * ((N + 127) / 128)) * sizeof(int);      // + queue heads, first list lengths, item list
+           (size_t)(MS_SCHED_INTS + 2 * (size_t)B * ((N + 127) / 128)) * sizeof(int);      // + queues, first list lengths, item list
 }
 
-// Work items of the persistent block-sparse kernel in descending order of their first stage-list length (counting sort on
-// MS_ITEM_BUCKETS coarse length classes: inside a class the items keep their order -- cloud by cloud, so that the workgroups
-// running at the same time still stream mostly the same clouds through the L2s). One workgroup.
-constexpr int MS_ITEM_BUCKETS = 16;
-__global__ __launch_bounds__(1024) void ms_sparse_item_order_kernel(const int* __restrict__ item_stages, int nitems, int nbx, int nst,
-                                                                    int* __restrict__ item_list) {
-    __shared__ int count[MS_ITEM_BUCKETS], start[MS_ITEM_BUCKETS];
+// The per-XCD item queues of the persistent block-sparse kernels (layout: ms_next_item) from the first stage-list length of
+// every item: clouds ranked by their total length and dealt to the 8 XCDs in snake order (equal shares of the work), every XCD's
+// queue = its clouds one after the other, heaviest first, each cloud's items longest first (the launch ends on short items; what
+// is left over at the end is taken by the XCDs that finish early). One workgroup; B <= MS_ORDER_MAX_CLOUDS.
+constexpr int MS_ORDER_MAX_CLOUDS = 4096;
+__global__ __launch_bounds__(1024) void ms_sparse_item_order_kernel(const int* __restrict__ item_stages, int B, int nbx,
+                                                                    int* __restrict__ item_list, int* __restrict__ sched) {
+    __shared__ int total[MS_ORDER_MAX_CLOUDS];
+    __shared__ unsigned short rank_of[MS_ORDER_MAX_CLOUDS];
+    __shared__ int nclouds[8], qstart[8];
     const int tid = threadIdx.x;
-    auto bucket = [&](int ns) { return MS_ITEM_BUCKETS - 1 - min(MS_ITEM_BUCKETS - 1, ns * MS_ITEM_BUCKETS / (nst + 1)); };
-    if (tid < MS_ITEM_BUCKETS) count[tid] = 0;
+    for (int c = tid; c < B; c += 1024) {
+        int t = 0;
+        for (int b = 0; b < nbx; ++b) t += item_stages[c * nbx + b];
+        total[c] = t;
+    }
     __syncthreads();
-    for (int i = tid; i < nitems; i += 1024) atomicAdd(&count[bucket(item_stages[i])], 1);
+    for (int c = tid; c < B; c += 1024) {                  // rank by (total descending, cloud ascending)
+        const int t = total[c];
+        int r = 0;
+        for (int o = 0; o < B; ++o) r += (total[o] > t || (total[o] == t && o < c)) ? 1 : 0;
+        rank_of[c] = (unsigned short)r;
+    }
+    if (tid < 8) {                                         // ranks 8 m + j go to XCD j (m even) or 7 - j (m odd)
+        int n = 0;
+        for (int r = 0; r < B; ++r) n += (((r >> 3) & 1) ? 7 - (r & 7) : (r & 7)) == tid ? 1 : 0;
+        nclouds[tid] = n;
+    }
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
-        for (int k = 0; k < MS_ITEM_BUCKETS; ++k) { start[k] = acc; acc += count[k]; }
+        for (int x = 0; x < 8; ++x) { qstart[x] = acc; acc += nclouds[x] * nbx; }
     }
     __syncthreads();
-    // stable scatter, one class after the other: a block-wide running offset per pass of 1024 items
-    __shared__ int wsum[16], base_sh;
-    for (int k = 0; k < MS_ITEM_BUCKETS; ++k) {
-        if (count[k] == 0) continue;                      // (uniform: shared value)
-        if (tid == 0) base_sh = start[k];
-        __syncthreads();
-        for (int i0 = 0; i0 < nitems; i0 += 1024) {
-            const int i = i0 + tid;
-            const bool in = i < nitems && bucket(item_stages[i]) == k;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
-            const int lane = tid & 63, w = tid >> 6;
-            if (lane == 0) wsum[w] = __builtin_popcountll(bal);
-            __syncthreads();
-            int off = base_sh;
-            for (int v = 0; v < w; ++v) off += wsum[v];
-            if (in) item_list[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = ((i / nbx) << 8) | (i % nbx);
-            __syncthreads();
-            if (tid == 0) {
-                int t = 0;
-                for (int v = 0; v < 16; ++v) t += wsum[v];
-                base_sh += t;
-            }
-            __syncthreads();
+    if (tid < 8) { sched[24 + tid] = qstart[tid]; sched[32 + tid] = nclouds[tid] * nbx; }
+    for (int i = tid; i < B * nbx; i += 1024) {
+        const int c = i / nbx, b = i - c * nbx;
+        const int r = rank_of[c], x = ((r >> 3) & 1) ? 7 - (r & 7) : (r & 7);
+        const int ns = item_stages[i];
+        int pos = 0;                                       // position among the cloud's items: (length descending, block ascending)
+        for (int o = 0; o < nbx; ++o) {
+            const int os = item_stages[c * nbx + o];
+            pos += (os > ns || (os == ns && o < b)) ? 1 : 0;
         }
+        item_list[qstart[x] + (r >> 3) * nbx + pos] = (c << 8) | b;
     }
 }
 
@@ -2265,36 +2286,36 @@ static int f16x_launch(int B, int N, int iters, const float* bw, const float* X,
     }
     const int nitems = nbx * B;
     const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
-    int* queue = sched;                                    // [4] queue heads | [nitems] first list lengths | [nitems] item list
-    int* item_stages = sched + 4;
+    int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
     int* item_list = item_stages + nitems;
-    hipError_t e = hipMemsetAsync(sched, 0, (size_t)(4 + nitems) * sizeof(int), stream);
+    const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
+    hipError_t e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
     ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     // first launch: every item builds its first stage list and reports its length; then the items are sorted by it
     ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
                                                                          tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr,
-                                                                         queue, item_stages);
-    ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, nitems, nbx, nst, item_list);
+                                                                         sched, 0, item_stages);
+    if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
         ms_iterate_d128_f16x_kernel<NW, false><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
-                                                                              tile_cosalpha, margin, stats, lowq, nitems, item_list,
-                                                                              queue + 1, nullptr);
+                                                                              tile_cosalpha, margin, stats, lowq, nitems, listed,
+                                                                              sched, listed ? 8 : 1, nullptr);
         ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
-                                                                             tile_cosalpha, margin, nullptr, lowq, nitems, item_list,
-                                                                             queue + 2, nullptr);
+                                                                             tile_cosalpha, margin, nullptr, lowq, nitems, listed,
+                                                                             sched, listed ? 16 : 2, nullptr);
     } else
         ms_iterate_d128_f16x_kernel<NW, true><<<grid, 64 * NW, sm, stream>>>(X, blob, newX, bw, flags, N, iters, skip_below, refblob,
-                                                                             tile_cosalpha, margin, stats, nullptr, nitems, item_list,
-                                                                             queue + 1, nullptr);
+                                                                             tile_cosalpha, margin, stats, nullptr, nitems, listed,
+                                                                             sched, listed ? 8 : 1, nullptr);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
 
 // form: 1 = round 2's 8-wave kernel on four-plane images (ms_iterate_d128_f16s_kernel); 2 / 3 = the 64-queries-per-wave kernel on
 // row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 0 = default
-constexpr int MS_SPARSE_DEFAULT_FORM = 2;
+constexpr int MS_SPARSE_DEFAULT_FORM = 1;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
@@ -2341,28 +2362,28 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
-    int* queue = sched;                                    // [4] queue heads | [nitems] first list lengths | [nitems] item list
-    int* item_stages = sched + 4;
+    int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
     int* item_list = item_stages + nitems;
-    e = hipMemsetAsync(sched, 0, (size_t)(4 + nitems) * sizeof(int), stream);
+    const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
+    e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
     ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, queue,
+        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
         item_stages);
-    ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, nitems, nbx, nst, item_list);
+    if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
         ms_iterate_d128_f16s_kernel<true, false><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, item_list, queue + 1,
-            nullptr);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
         ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, item_list, queue + 2,
-            nullptr);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
+            listed ? 16 : 2, nullptr);
     } else
         ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, item_list, queue + 1,
-            nullptr);
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -1026,6 +1026,10 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_f16w_kernel(const float* __
 #ifndef F16S_NBUF
 #define F16S_NBUF 3                                    // stage buffers of the sparse kernel (4 fit -- 4 x 37 KiB + 7 KiB of tables <= 160 KiB -- and change nothing: 51.1 vs 50.5 ms)
 #endif
+#ifndef F16S_NBUF_RM_N
+#define F16S_NBUF_RM_N 6
+#endif
+constexpr int F16S_NBUF_RM = F16S_NBUF_RM_N;       // stage buffers on row-major images (6 x 17 KiB)
 constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
 
 constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
@@ -1633,7 +1637,9 @@ __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
 // The pipeline is primed and drained once per iteration (2 stage copies exposed); lists are walked in alternating
 // direction so that an iteration starts on the stages the previous one left in L2.
 // What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
-template <bool STAGGER, bool PL = true>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
+// RM: row-major stage images (StageLayoutN: 17 KiB instead of the four-plane 37 KiB -- half the L2 / fabric traffic and DMA issue,
+// six stage buffers instead of three), second-product operands by transpose reads like ms_iterate_f16w_kernel
+template <bool STAGGER, bool PL = true, bool RM = false>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
 __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
@@ -1641,10 +1647,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
     int* __restrict__ sched, int head0, int* __restrict__ item_stages) {
     using L = StageLayout<32>;
-    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = L::STAGE, NPIECE = L::STAGE / 1024;
+    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = RM ? StageLayoutN::STAGE : L::STAGE, NPIECE = STAGE / 1024;
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    static_assert(StageLayoutN::XROW == L::XROW && StageLayoutN::OFF_XL == L::OFF_XL, "the X planes of both layouts coincide");
     constexpr int MAXW = F16S_MAXW;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [F16S_NBUF][STAGE]
+    constexpr int NBUF = RM ? F16S_NBUF_RM : F16S_NBUF;
+    constexpr int REFG = NBUF * STAGE / F16S_REFBYTES < F16S_REFGROUP ? NBUF * STAGE / F16S_REFBYTES : F16S_REFGROUP;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE]
     __shared__ unsigned long long wmask[8][MAXW];
     __shared__ int slist[512];
     __shared__ int wcount[8];
@@ -1704,6 +1713,9 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             ql[ks][i] = (h16)(v[i] - (float)h);
         }
     };
+    // Q operand of k-step ks on lane half hi: four-plane images: features 16 ks + 4 hi + {0..3, 8..11} (the order the accumulator
+    // rows come in: the row update needs no exchange); row-major images: features 16 ks + 8 hi + 0..7 (the image's own order: the
+    // row update exchanges four values per k-step with the other lane half, like ms_iterate_f16w_kernel)
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1711,18 +1723,28 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             float v[8];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + 8 * (2 * j + g) + 4 * hi);
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + (RM ? 16 * j + 8 * hi + 4 * g : 8 * (2 * j + g) + 4 * hi));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
             }
             split_q(2 * c + j, v);
         }
 
-    static_assert(NPIECE == 37, "piece distribution below is written for 37 pieces");
+    static_assert(NPIECE == (RM ? 17 : 37), "piece distribution below is written for 37 / 17 pieces");
     const unsigned lane16 = lane * 16;
     auto stage_dma = [&](int st, int buf) {
         const uint8_t* src = blob_c + (size_t)st * STAGE;
         uint8_t* dst = lds + buf * STAGE;
+        if constexpr (RM) {                               // 17 pieces dealt round-robin to the 8 waves
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int pc = wave + 8 * i;
+                if (pc < NPIECE)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024 + lane16),
+                                                     (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+            }
+            return;
+        }
         const auto g = (const __attribute__((address_space(1))) void*)(src + wave * 4096 + lane16);
         const auto l = (__attribute__((address_space(3))) void*)(dst + wave * 4096);
         __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
@@ -1736,12 +1758,28 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     };
 
     h16x8 fa[4], fb[4];
-    const int xoff = li * XROW + hi * 16;
-    const int toff = li * TROW + hi * 16;
+    const int xoff_nat = li * XROW + hi * 16;             // natural row order (reference planes)
+    // RM: key rows in sigma order for the first product, transpose reads for the second (ms_iterate_d128_f16r_kernel's scheme)
+    const int xoff = RM ? (16 * (li >> 4) + 4 * (li & 3) + ((li >> 2) & 3)) * XROW + hi * 16 : xoff_nat;
+    const int toff = RM ? (4 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) : li * TROW + hi * 16;
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
+        typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+        const v8s both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(h16x8, both);
+    };
     auto ring_load = [&](int t, const uint8_t* base) {
         if (t < 8) {
             fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
             fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else if constexpr (RM) {
+            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            fa[t & 3] = tr8(base + OFF_XH, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
         } else {
             const int c = (t - 8) >> 1, j = (t - 8) & 1;
             fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
@@ -1784,12 +1822,13 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
                         const int r = 4 * g + u;
                         v[u] = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
                     }
-                    *(f32x4*)(keep + 32 * c + 8 * g + 4 * hi) = v;
+                    // (RM: Q-operand order -- element i of k-step 2 c + (g >> 1) -- read back by the same lane in the same order)
+                    *(f32x4*)(keep + (RM ? 32 * c + 16 * (g >> 1) + 8 * hi + 4 * (g & 1) : 32 * c + 8 * g + 4 * hi)) = v;
                 }
         }
         // ---- (1) + (2): this wave's queries against all tile references -> its stage mask
-        for (int g0 = 0; g0 < nrs; g0 += F16S_REFGROUP) {
-            const int ng = min(F16S_REFGROUP, nrs - g0);
+        for (int g0 = 0; g0 < nrs; g0 += REFG) {
+            const int ng = min(REFG, nrs - g0);
             if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
             for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
                 const int im = pc / 9, piece = pc - 9 * im;
@@ -1800,7 +1839,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             for (int im = 0; im < ng; ++im) {
-                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff;
+                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff_nat;
                 f32x16 sr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sr[r] = 0.f;
@@ -1861,9 +1900,9 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         // ---- (4) the pipeline over the list
         const bool fwd = (it & 1) == 0;
         auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
-        if (ns > 0) stage_dma(entry(0), 0);
-        if (ns > 1) stage_dma(entry(1), 1);
-        if (F16S_NBUF > 3 && ns > 2) stage_dma(entry(2), 2);
+#pragma unroll
+        for (int j0 = 0; j0 < NBUF - 1; ++j0)
+            if (j0 < ns) stage_dma(entry(j0), j0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ns > 0) {
@@ -1873,7 +1912,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         int buf = 0;
         for (int j = 0; j < ns; ++j) {
             const uint8_t* base = lds + buf * STAGE;
-            const int nbuf = buf == F16S_NBUF - 1 ? 0 : buf + 1;
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
             const uint8_t* nbase = lds + nbuf * STAGE;
             const int st = entry(j);
             const int key0 = st * 32;
@@ -1899,7 +1938,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
                 if (key0 + 32 > N) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (key0 + mfma_row(r, hi) >= N) p[r] = 0.f;
+                        if (key0 + (RM ? sigma_row(mfma_row(r, hi)) : mfma_row(r, hi)) >= N) p[r] = 0.f;
                 }
                 float pmax = 0.f;
 #pragma unroll
@@ -1923,7 +1962,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // B_j
             // entry j + NBUF - 1 goes into the buffer entry j - 1 has left (every wave is past it: it passed B_j)
-            if (j + F16S_NBUF - 1 < ns) stage_dma(entry(j + F16S_NBUF - 1), buf == 0 ? F16S_NBUF - 1 : buf - 1);
+            if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
             if (late && need) first_product_and_weights();
 
             if (live) {
@@ -1950,21 +1989,64 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         const float Dinv = UNSCALE_O / rs;
         float n2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
+            float qacc[16];                               // the current row in accumulator order
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;
+                    if (RM) {
+                        const float keep_ = hi ? e1 : e0, send = hi ? e0 : e1;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        qacc[8 * j + u] = hi ? recv : keep_;
+                        qacc[8 * j + 4 + u] = hi ? keep_ : recv;
+                    } else {
+                        qacc[8 * j + u] = e0;
+                        qacc[8 * j + 4 + u] = e1;
+                    }
+                }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float q = ((float)qh[2 * c + (r >> 3)][r & 7] + (float)ql[2 * c + (r >> 3)][r & 7]) * UNSCALE_Q;
+                const float q = qacc[r];
                 const float m = o[c][r] * Dinv - q;
                 const float nq = q + m;
                 o[c][r] = nq;
                 n2 += nq * nq;
             }
+        }
         n2 += xor32(n2);
         const float nrm = sqrtf(n2);
         if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;       // see ms_iterate_d128_f16q_kernel
         if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
             float ch2 = 0.f;
-            if (qrow < N) {
+            if (RM) {                                     // new Q operand (exchange with the other lane half) and its distance to the parked row
+                const float* kept = newX + ((size_t)cloud * N + qrow_c) * 128 + 8 * hi;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float a_ = (o[c][8 * j + u] / nrm) * SCALE_X, b_ = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                            const float keep_ = hi ? b_ : a_, send = hi ? a_ : b_;
+                            const float recv = __shfl_xor(send, 32, 64);
+                            v[u] = hi ? recv : keep_;
+                            v[4 + u] = hi ? keep_ : recv;
+                        }
+                        const f32x4 k0 = *(const f32x4*)(kept + 16 * (2 * c + j));
+                        const f32x4 k1 = *(const f32x4*)(kept + 16 * (2 * c + j) + 4);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d0 = v[u] * UNSCALE_Q - k0[u], d1 = v[4 + u] * UNSCALE_Q - k1[u];
+                            ch2 = fmaf(d0, d0, fmaf(d1, d1, ch2));
+                        }
+                        split_q(2 * c + j, v);
+                    }
+                if (qrow >= N) ch2 = 0.f;
+            } else if (qrow < N) {
                 const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
                 const float inv = 1.0f / nrm;
 #pragma unroll
@@ -1998,15 +2080,17 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
                     }
             }
         } else {
+            if (!RM) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v[8];
+                    for (int j = 0; j < 2; ++j) {
+                        float v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
-                    split_q(2 * c + j, v);
-                }
+                        for (int i = 0; i < 8; ++i) v[i] = (o[c][8 * j + i] / nrm) * SCALE_X;
+                        split_q(2 * c + j, v);
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -2313,13 +2397,74 @@ static int f16x_launch(int B, int N, int iters, const float* bw, const float* X,
     return SED_OK;
 }
 
+// forms 1 / 4: the 8-wave kernel with per-wave block skipping on four-plane (RM = false) or row-major (RM = true) stage images
+template <bool RM>
+static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                       float margin, unsigned long long* stats, int digits, int* sched, hipStream_t stream) {
+    using L = StageLayout<32>;
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
+    constexpr int sm = RM ? F16S_NBUF_RM * StageLayoutN::STAGE : F16S_NBUF * L::STAGE;
+    hipError_t e = hipSuccess;
+    static bool attr = false;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true, RM>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false, RM>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int nbx = (N + 255) / 256, nitems = nbx * B;
+    if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
+    static int slots = 0;                                  // resident workgroups: one of 512 threads per CU
+    if (!slots) {
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
+    int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
+    int* item_list = item_stages + nitems;
+    const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
+    e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    if (RM) {
+        ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    } else {
+        ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    }
+    ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
+        item_stages);
+    if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
+    if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
+        ms_iterate_d128_f16s_kernel<true, false, RM><<<grid, 512, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
+        ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
+            listed ? 16 : 2, nullptr);
+    } else
+        ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
 // form: 1 = round 2's 8-wave kernel on four-plane images (ms_iterate_d128_f16s_kernel); 2 / 3 = the 64-queries-per-wave kernel on
-// row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 0 = default
-constexpr int MS_SPARSE_DEFAULT_FORM = 1;
+// row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 4 = the 8-wave kernel on row-major images; 0 = default
+constexpr int MS_SPARSE_DEFAULT_FORM = 4;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
-    using L = StageLayout<32>;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
     if (form == 0) form = MS_SPARSE_DEFAULT_FORM;
@@ -2340,50 +2485,9 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     if (form == 3)
         return f16x_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
                               stats, digits, sched, stream);
-    static bool attr = false;
-    if (!attr) {
-        e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, F16S_NBUF * L::STAGE);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-    const int nbx = (N + 255) / 256, nitems = nbx * B;
-    if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
-    static int slots = 0;                                  // resident workgroups: one of 512 threads per CU
-    if (!slots) {
-        int dev = 0;
-        e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return (int)e;
-    }
-    const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
-    int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
-    int* item_list = item_stages + nitems;
-    const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
-    e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
-    if (e != hipSuccess) return (int)e;
-    ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
-    ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
-    ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
-        item_stages);
-    if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
-    if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
-        ms_iterate_d128_f16s_kernel<true, false><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
-            listed ? 8 : 1, nullptr);
-        ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
-            listed ? 16 : 2, nullptr);
-    } else
-        ms_iterate_d128_f16s_kernel<true, true><<<grid, 512, F16S_NBUF * L::STAGE, stream>>>(
-            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
-            listed ? 8 : 1, nullptr);
-    SED_LAUNCH_CHECK();
-    return SED_OK;
+    if (form == 4)
+        return f16s_launch<true>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                                 stats, digits, sched, stream);
+    return f16s_launch<false>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                              stats, digits, sched, stream);
 }

@@ -342,7 +342,7 @@ def test_block_sparse_schedule(T):
     args = lambda skip, d, digits: (2, 3000, d, 5, ptr(bwr), ptr(prep["Xs"]), ptr(out), skip, ptr(prep["ref"]),
                                     ptr(prep["cosalpha"]), 2e-3, ptr(ws), nws, None, digits, 0, stream())
     assert lib.sed_ms_iterate_bounds_f16_f32(*args(0.0, 128, 1)) == -1
-    assert lib.sed_ms_iterate_bounds_f16_f32(*args(-30.0, 128, 3)) == -1
+    assert lib.sed_ms_iterate_bounds_f16_f32(*args(-30.0, 128, 3)) == -1                      # weight_digits 3
     assert lib.sed_ms_iterate_bounds_f16_f32(*args(-30.0, 64, 1)) == -2
 
 

@@ -14,28 +14,28 @@ def edge_cls_loss(edges_pred, edges_label, bce_W):
 def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
     """Pull every feature to within t_pull of its segment centre, push centres t_push apart.
     pred_feat [B,M,K], gt_label [B,M] (labels >= -1) -> (loss [1], pull [1], push [1])."""
+    # all clouds in one set of launches: segment statistics by one-hot products over the label range of the batch (the reference
+    # loops over clouds and segments in Python; round 2 looped over clouds -- torch.unique + ~15 small launches each, forward and
+    # backward). Segments a cloud does not have are masked out; the terms are the reference's. (A scatter-add would do too, but
+    # its fp32 atomics -- forward and in the backward of the gather -- make the gradients differ from run to run, and the training
+    # step is otherwise bit-reproducible.)
     B = pred_feat.shape[0]
-    dev = pred_feat.device
-    pull = torch.zeros(1, device=dev)
-    push = torch.zeros(1, device=dev)
-    for i in range(B):
-        # segment statistics by one-hot products instead of the reference's per-segment Python loop (same terms; a
-        # scatter-add / index_add_ would do too, but its fp32 atomics -- forward and in the backward of C[inv] -- make the
-        # gradients differ from run to run, and the training step is otherwise bit-reproducible)
-        _, inv, cnt = torch.unique(gt_label[i], return_inverse=True, return_counts=True)
-        S = cnt.shape[0]
-        cntf = cnt.to(pred_feat.dtype)
-        onehot = (inv[None, :] == torch.arange(S, device=dev)[:, None]).to(pred_feat.dtype)        # [S, M]
-        C = (onehot @ pred_feat[i]) / cntf[:, None]
-        excess = F.relu(torch.norm(pred_feat[i] - onehot.t() @ C, 2, dim=1) - t_pull)
-        per_seg = (onehot @ excess) / cntf
-        pull = pull + per_seg.sum() / S
-        if S == 1:
-            continue
-        dist = torch.norm(C[:, None, :] - C[None, :, :], 2, dim=2)
-        off = dist[~torch.eye(S, dtype=torch.bool, device=dev)]
-        push = push + F.relu(t_push - off).mean()
-    pull, push = pull / B, push / B
+    dev, dt = pred_feat.device, pred_feat.dtype
+    lab = gt_label - gt_label.min()
+    L = int(lab.max().item()) + 1
+    onehot = (lab[:, None, :] == torch.arange(L, device=dev)[None, :, None]).to(dt)                    # [B, L, M]
+    cnt = onehot.sum(2)                                                                                # [B, L]
+    present = cnt > 0
+    S = present.sum(1).to(dt)                                                                          # segments per cloud
+    cnt1 = cnt.clamp(min=1.0)
+    C = torch.bmm(onehot, pred_feat) / cnt1[:, :, None]                                                # [B, L, K] centres
+    excess = F.relu(torch.norm(pred_feat - torch.bmm(onehot.transpose(1, 2), C), 2, dim=2) - t_pull)   # [B, M]
+    per_seg = torch.bmm(onehot, excess[:, :, None]).squeeze(2) / cnt1                                  # 0 for absent segments
+    pull = (per_seg.sum(1) / S).sum().reshape(1) / B
+    dist = torch.norm(C[:, :, None, :] - C[:, None, :, :], 2, dim=3)                                   # [B, L, L]
+    pair = present[:, :, None] & present[:, None, :] & ~torch.eye(L, dtype=torch.bool, device=dev)[None]
+    npair = (S * (S - 1.0)).clamp(min=1.0)                                                             # S = 1: no pairs, term 0
+    push = ((F.relu(t_push - dist) * pair.to(dt)).sum((1, 2)) / npair).sum().reshape(1) / B
     return pull + push, pull, push
 
 

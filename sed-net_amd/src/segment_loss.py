@@ -55,19 +55,30 @@ class EmbeddingLoss:
             plan.append((off, rows.shape, np.asarray(pairs)))
             flat.append(rows.reshape(-1).astype(np.int64) + i * N)
             off += rows.size
+        # the tensor work of ALL clouds in one set of launches (round 3: one set per cloud was ~20 launches forward and as many
+        # backward, x 32 clouds: a third of the step's 3000 launch-bound tiny kernels). Pairs are grouped by their sample count
+        # ns (one group unless a cloud has > N / 29 segments) and processed in blocks of <= 256 pairs ([256, ns, ns, D] differences).
         total = torch.zeros(1, device=dev)
         if plan:
             G = out.reshape(B * N, -1)[torch.as_tensor(np.concatenate(flat), device=dev)]        # [sum nk ns, D]
-        for o, (nk, ns), pairs in plan:
-            seg = G[o:o + nk * ns].view(nk, ns, -1)
-            pr = torch.as_tensor(pairs, device=dev)
-            a, b = seg[pr[:, 0]], seg[pr[:, 1]]                                                   # [P, ns, D]
-            d_pos = ((a[:, :, None] - a[:, None]) ** 2).sum(3)
-            d_neg = ((a[:, :, None] - b[:, None]) ** 2).sum(3)
-            viol = F.relu(d_pos - d_neg + self.margin)                                            # [P, ns, ns]
-            hinge = viol.sum((1, 2)) - torch.diagonal(viol, dim1=1, dim2=2).sum(1)                # anchor == positive
-            active = ((viol > 0).sum((1, 2)) + 1.0).float().detach()
-            total = total + (hinge / active).sum() / (len(pairs) + 1e-8)
+            groups = {}
+            for o, (nk, ns), pairs in plan:
+                ar = np.arange(ns)[None, :]
+                ai = o + pairs[:, :1] * ns + ar                                                   # [P, ns] rows of G
+                bi = o + pairs[:, 1:2] * ns + ar
+                w = np.full(len(pairs), 1.0 / (len(pairs) + 1e-8), np.float32)
+                g = groups.setdefault(ns, [[], [], []])
+                g[0].append(ai); g[1].append(bi); g[2].append(w)
+            for ns, (ai, bi, w) in groups.items():
+                ai, bi, w = (torch.as_tensor(np.concatenate(x), device=dev) for x in (ai, bi, w))
+                for p0 in range(0, ai.shape[0], 256):
+                    a, b = G[ai[p0:p0 + 256]], G[bi[p0:p0 + 256]]                                 # [P, ns, D]
+                    d_pos = ((a[:, :, None] - a[:, None]) ** 2).sum(3)
+                    d_neg = ((a[:, :, None] - b[:, None]) ** 2).sum(3)
+                    viol = F.relu(d_pos - d_neg + self.margin)                                    # [P, ns, ns]
+                    hinge = viol.sum((1, 2)) - torch.diagonal(viol, dim1=1, dim2=2).sum(1)        # anchor == positive
+                    active = ((viol > 0).sum((1, 2)) + 1.0).float().detach()
+                    total = total + ((hinge / active) * w[p0:p0 + 256]).sum()
         return total / (B - single + 1e-8)
 
 

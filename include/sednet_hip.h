@@ -156,9 +156,10 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
  * images of rows and references; stats: NULL or 5 device uint64 counters that are ADDED to (stage visits of workgroups,
  * first products of waves, second products of waves, stages x iterations per wave = the dense count, mask / list
  * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.005 rad). weight_digits: as in
- * sed_ms_options_t. form: 0 = default (4); 1 = 8-wave workgroups of 32-query waves on four-plane stage images (37 KiB per 32 keys),
+ * sed_ms_options_t. form: 0 = default (5); 1 = 8-wave workgroups of 32-query waves on four-plane stage images (37 KiB per 32 keys),
  * a wave skips the blocks it does not need (round 2's kernel); 4 = the same kernel on row-major stage images (17 KiB: half the
- * L2 / fabric traffic, second-product operands by LDS transpose reads); 2 / 3 = 64 queries per wave (one wave per SIMD) on
+ * L2 / fabric traffic, second-product operands by LDS transpose reads); 5 = form 4 with 4-wave workgroups (128 query rows, two
+ * workgroups per CU: smaller unions of the waves' stage lists, two independent barrier domains); 2 / 3 = 64 queries per wave on
  * row-major images with 2- / 4-wave workgroups, all waves of a workgroup compute every listed stage on the dense kernel's software
  * pipeline (more MFMAs, fewer stalls: slower on a power-limited chip, kept selectable). All forms skip by the same rule (rows differ
  * by summation order only) and run as PERSISTENT workgroups: a first launch builds every work item's first stage list and reports

@@ -1639,8 +1639,10 @@ __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
 // What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1).
 // RM: row-major stage images (StageLayoutN: 17 KiB instead of the four-plane 37 KiB -- half the L2 / fabric traffic and DMA issue,
 // six stage buffers instead of three), second-product operands by transpose reads like ms_iterate_f16w_kernel
-template <bool STAGGER, bool PL = true, bool RM = false>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
-__global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
+// NW: waves per workgroup: 8 (256 query rows, one workgroup per CU) or 4 (128 rows, two per CU: smaller unions of the waves' stage
+// lists, two independent barrier domains per CU, twice the stage copies)
+template <bool STAGGER, bool PL = true, bool RM = false, int NW = 8>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
+__global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
     const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
@@ -1651,21 +1653,22 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
     static_assert(StageLayoutN::XROW == L::XROW && StageLayoutN::OFF_XL == L::OFF_XL, "the X planes of both layouts coincide");
     constexpr int MAXW = F16S_MAXW;
-    constexpr int NBUF = RM ? F16S_NBUF_RM : F16S_NBUF;
+    constexpr int NBUF = RM ? (NW == 8 ? F16S_NBUF_RM : 4) : F16S_NBUF;
     constexpr int REFG = NBUF * STAGE / F16S_REFBYTES < F16S_REFGROUP ? NBUF * STAGE / F16S_REFBYTES : F16S_REFGROUP;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE]
-    __shared__ unsigned long long wmask[8][MAXW];
+    __shared__ unsigned long long wmask[NW][MAXW];
     __shared__ int slist[512];
-    __shared__ int wcount[8];
+    __shared__ int wcount[NW];
     __shared__ int item_sh;
-    __shared__ float wmoved[8];
+    __shared__ float wmoved[NW];
     __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 31, hi = lane >> 5;
-    const bool late = STAGGER && wave >= 4;
+    const bool late = STAGGER && wave >= NW / 2;
     // persistent workgroups over a sorted item list: see ms_iterate_d128_f16x_kernel (an item here = 256 query rows of a cloud)
-    const int nbx = (N + 255) >> 8;
+    constexpr int QB = 32 * NW;                           // query rows per workgroup
+    const int nbx = (N + QB - 1) / QB;
     for (;;) {
     __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
     if (tid == 0) item_sh = ms_next_item(sched, item_list, head0, nitems, nbx);
@@ -1682,7 +1685,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
     const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
     const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
-    const int qrow = bx * 256 + wave * 32 + li;
+    const int qrow = bx * QB + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
 
     const float b = bw[cloud];
@@ -1693,7 +1696,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
     {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
         const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
         const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
-        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 512) {
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 64 * NW) {
             float v = 3.0e38f;                           // references of tiles past the end: never near
             const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
             if (t < nst) {
@@ -1737,8 +1740,8 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         uint8_t* dst = lds + buf * STAGE;
         if constexpr (RM) {                               // 17 pieces dealt round-robin to the 8 waves
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int pc = wave + 8 * i;
+            for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+                const int pc = wave + NW * i;
                 if (pc < NPIECE)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024 + lane16),
                                                      (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
@@ -1806,7 +1809,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         if (it > 0) {
             float mx = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) mx = fmaxf(mx, wmoved[w]);
+            for (int w = 0; w < NW; ++w) mx = fmaxf(mx, wmoved[w]);
             remake = !(mx <= F16S_DELTA);
         }
         if (remake) {
@@ -1830,7 +1833,7 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         for (int g0 = 0; g0 < nrs; g0 += REFG) {
             const int ng = min(REFG, nrs - g0);
             if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
-            for (int pc = wave; pc < ng * 9; pc += 8) {       // 1 KiB pieces: image pc / 9, piece pc % 9
+            for (int pc = wave; pc < ng * 9; pc += NW) {      // 1 KiB pieces: image pc / 9, piece pc % 9
                 const int im = pc / 9, piece = pc - 9 * im;
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
@@ -1864,28 +1867,30 @@ __global__ __launch_bounds__(512, 1) void ms_iterate_d128_f16s_kernel(
         }
         if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
         __syncthreads();
-        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s
-        {
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s (s + 64 NW, .. in further passes)
+        ns = 0;
+        for (int s0 = 0; s0 < nst; s0 += 64 * NW) {
+            const int st = s0 + tid;
             bool need = false;
-            if (tid < nst) {
-                const int w = tid >> 6, sh = tid & 63;
+            if (st < nst) {
+                const int w = st >> 6, sh = st & 63;
                 unsigned long long any = 0ull;
 #pragma unroll
-                for (int v = 0; v < 8; ++v) any |= wmask[v][w];
+                for (int v = 0; v < NW; ++v) any |= wmask[v][w];
                 need = (any >> sh) & 1ull;
             }
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (s0 > 0) __syncthreads();                  // wcount of the previous pass has been read
             if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
             __syncthreads();
-            int base = 0;
-            ns = 0;
+            int base = ns;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const int cnt = wcount[w];
                 if (w < wave) base += cnt;
                 ns += cnt;
             }
-            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tid;
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = st;
         }
         __syncthreads();
         ns = __builtin_amdgcn_readfirstlane(ns);
@@ -2398,34 +2403,36 @@ static int f16x_launch(int B, int N, int iters, const float* bw, const float* X,
 }
 
 // forms 1 / 4: the 8-wave kernel with per-wave block skipping on four-plane (RM = false) or row-major (RM = true) stage images
-template <bool RM>
+template <bool RM, int NW = 8>
 static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
                        uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                        float margin, unsigned long long* stats, int digits, int* sched, hipStream_t stream) {
     using L = StageLayout<32>;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
-    constexpr int sm = RM ? F16S_NBUF_RM * StageLayoutN::STAGE : F16S_NBUF * L::STAGE;
+    constexpr int sm = RM ? (NW == 8 ? F16S_NBUF_RM : 4) * StageLayoutN::STAGE : F16S_NBUF * L::STAGE;
+    static_assert(RM || NW == 8, "four-plane images: 8-wave workgroups only (LDS)");
     hipError_t e = hipSuccess;
     static bool attr = false;
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true, RM>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true, RM, NW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false, RM>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false, RM, NW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    const int nbx = (N + 255) / 256, nitems = nbx * B;
+    const int nbx = (N + 32 * NW - 1) / (32 * NW), nitems = nbx * B;
     if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
-    static int slots = 0;                                  // resident workgroups: one of 512 threads per CU
+    static int slots = 0;                                  // resident workgroups: 8 waves of 256 registers per CU
     if (!slots) {
         int dev = 0;
         e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return (int)e;
+        slots *= 8 / NW;
     }
     const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
     int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
@@ -2440,19 +2447,19 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
         ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
         ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     }
-    ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+    ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
         X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
         item_stages);
     if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
-        ms_iterate_d128_f16s_kernel<true, false, RM><<<grid, 512, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<true, false, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
-        ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
             listed ? 16 : 2, nullptr);
     } else
-        ms_iterate_d128_f16s_kernel<true, true, RM><<<grid, 512, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
     SED_LAUNCH_CHECK();
@@ -2460,8 +2467,8 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
 }
 
 // form: 1 = round 2's 8-wave kernel on four-plane images (ms_iterate_d128_f16s_kernel); 2 / 3 = the 64-queries-per-wave kernel on
-// row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 4 = the 8-wave kernel on row-major images; 0 = default
-constexpr int MS_SPARSE_DEFAULT_FORM = 4;
+// row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 4 = the 8-wave kernel on row-major images; 5 = the same with 4-wave workgroups; 0 = default
+constexpr int MS_SPARSE_DEFAULT_FORM = 5;
 int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
@@ -2485,6 +2492,9 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     if (form == 3)
         return f16x_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
                               stats, digits, sched, stream);
+    if (form == 5)
+        return f16s_launch<true, 4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                                    stats, digits, sched, stream);
     if (form == 4)
         return f16s_launch<true>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
                                  stats, digits, sched, stream);

@@ -28,7 +28,7 @@ dms, dense = t(lambda: ops.ms_iterate(X, bw, 50))
 ops.ms_set_variant("auto")
 print(f"dense all {B} clouds {dms:.1f} ms")
 prep_ms, prep = t(lambda: ops.ms_sparse_prepare(X))
-for form, groups_per_wg in ((1, 8), (4, 8), (2, 4)):
+for form, groups_per_wg in ((4, 8), (5, 4), (2, 4)):
     ops.MS_SPARSE_FORM = form
     for skip in (-30.0,) if form != 2 else (-30.0, -25.0):
         stats = torch.zeros(5, dtype=torch.int64, device=dev)

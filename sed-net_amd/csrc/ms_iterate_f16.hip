@@ -2403,6 +2403,9 @@ static int f16x_launch(int B, int N, int iters, const float* bw, const float* X,
 }
 
 // forms 1 / 4: the 8-wave kernel with per-wave block skipping on four-plane (RM = false) or row-major (RM = true) stage images
+#ifndef F16S_STAG
+#define F16S_STAG true
+#endif
 template <bool RM, int NW = 8>
 static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
                        uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
@@ -2416,10 +2419,10 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, true, RM, NW>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<true, false, RM, NW>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
         attr = true;
@@ -2447,19 +2450,19 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
         ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
         ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     }
-    ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+    ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
         X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
         item_stages);
     if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
-        ms_iterate_d128_f16s_kernel<true, false, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
-        ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
             listed ? 16 : 2, nullptr);
     } else
-        ms_iterate_d128_f16s_kernel<true, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
     SED_LAUNCH_CHECK();

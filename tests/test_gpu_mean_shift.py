@@ -444,6 +444,47 @@ def test_every_schedule_is_bit_reproducible(T):
         assert all(T.equal(a, b) for a, b in zip(o0, ops.ms_pivot_order(X)))
 
 
+def test_every_form_of_the_block_sparse_kernel(T):
+    """sed_ms_iterate_bounds_f16_f32's `form` argument: 1 (8 waves, four-plane images), 4 (8 waves, row-major images), 5 (4 waves,
+    row-major: the default), 2 / 3 (64 queries per wave, 2- / 4-wave workgroups). All skip by the same rule: rows within the dense
+    kernel's tolerance for every form, with one and with two weight digits; what a WAVE computes does not depend on the workgroup
+    it sits in, so forms 4 and 5 return the same bits; the counters are consistent (second products <= first products <= listed
+    stages x waves; the dense count is the same for every form); ragged N and a flagged (non-unit) cloud in the batch."""
+    from sednet_hip import ops, synth
+    Xs = np.stack([synth.clustered_embedding(N=4999, d=128, n_clusters=9 + 2 * c, sigma=0.015, seed=300 + c)[0] for c in range(3)])
+    Xs[2] *= np.float32(1.2)                                   # flagged by the split kernel: the exact fp32 kernel takes it
+    X = dev(T, Xs)
+    bw = T.full((3,), 0.14, device="cuda")
+    try:
+        ops.ms_set_variant("f16")
+        dense = ops._ms_iterate_dense(X, bw, 12)
+        ops.ms_set_variant("batched")
+        exact = ops._ms_iterate_dense(X, bw, 12)
+    finally:
+        ops.ms_set_variant("auto")
+    rows, counts = {}, {}
+    try:
+        for digits in (2, 1):
+            ops.ms_set_weight_digits(digits)
+            for form in (1, 2, 3, 4, 5):
+                ops.MS_SPARSE_FORM = form
+                st = T.zeros(5, dtype=T.int64, device="cuda")
+                got = ops.ms_iterate_sparse(X, bw, 12, stats=st)
+                np.testing.assert_allclose(got[:2].cpu().numpy(), dense[:2].cpu().numpy(), atol=4e-6 if digits == 2 else 2e-5,
+                                           err_msg=f"form {form}, {digits} digit(s)")
+                np.testing.assert_allclose(got[2].cpu().numpy(), exact[2].cpu().numpy(), atol=2e-5)
+                assert T.equal(got, ops.ms_iterate_sparse(X, bw, 12)), form              # same bits run after run
+                rows[digits, form], counts[digits, form] = got, st.cpu().numpy()
+            assert T.equal(rows[digits, 4], rows[digits, 5])
+            for form in (1, 2, 3, 4, 5):
+                c = counts[digits, form]
+                assert c[3] == counts[digits, 1][3] and 0 < c[2] <= c[1] <= c[3] and c[4] > 0, (form, c)
+            assert (counts[digits, 4][1:3] == counts[digits, 5][1:3]).all() and counts[digits, 5][0] > 0
+    finally:
+        ops.MS_SPARSE_FORM = 0
+        ops.ms_set_weight_digits(2)
+
+
 def test_sparse_preparation_kernels_keep_the_invariants_the_skipping_rule_needs(T):
     """sed_ms_sparse_prepare_f32 (pivots, k-means step, super-groups, stable sort, tile references -- HIP kernels, no library
     calls): the order is a permutation, Xs are the rows in that order, every reference is a unit vector (or zero for an empty

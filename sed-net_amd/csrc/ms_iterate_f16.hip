@@ -1033,7 +1033,10 @@ constexpr int F16S_NBUF_RM = F16S_NBUF_RM_N;       // stage buffers on row-major
 constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
 
 constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load: 12 x 9 KiB head planes <= 3 stage buffers
-constexpr float F16S_DELTA = 0.005f;              // masks stay valid while no query has turned by more than this (rad)
+#ifndef F16S_DELTA_V
+#define F16S_DELTA_V 0.005f
+#endif
+constexpr float F16S_DELTA = F16S_DELTA_V;              // masks stay valid while no query has turned by more than this (rad)
 constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
 
 // ------------------------------------------------------------------------------------------------------------

@@ -150,6 +150,7 @@ def cpu_baseline(args):
 
 def roofline_block(timers, N, iterations, digits, counters=None):
     """the mean-shift iteration kernel that took most of the timed region -> roofline dict (None if no launch was recorded)"""
+    from sednet_hip import ops
     groups = {}
     for name, s, e, meta in timers:
         if name in ("ms_iterate", "ms_iterate_sparse"):
@@ -193,7 +194,7 @@ def roofline_block(timers, N, iterations, digits, counters=None):
             blk["executed_share_of_dense_work"] = {"first_products": round(c[1] / c[3], 4), "second_products": round(c[2] / c[3], 4)}
             blk["executed_f16_mfma_tflops"] = round(ex_flops / (tot_ms * 1e-3) / 1e12, 1)
             blk["executed_frac_of_f16_peak"] = round(ex_flops / (tot_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4)
-            blk["note"] += ("; block-sparse schedule: 32 x 32 blocks whose kernel weights are all <= e^-30 are skipped (frac > 1 = "
+            blk["note"] += (f"; block-sparse schedule: 32 x 32 blocks whose kernel weights are all <= e^{ops.MS_SPARSE_SKIP:g} = 2^-39 (what fp16(2^14 p) rounds to zero in the dense kernel too) are skipped (frac > 1 = "
                             "work the reference does and this kernel proves negligible); executed_* = the MFMAs it really issues")
     pmc = os.path.join(ROOT, "profiles", "r03_pmc_ms_iterate.json")
     if os.path.exists(pmc):

@@ -235,10 +235,15 @@ def ms_bandwidth(X, K, min_bw=0.003):
 
 # Block-sparse mean-shift schedule (d = 128, ms_iterate_sparse): "auto" = per cloud, by a density probe (ms_near_fraction:
 # the share of sampled row pairs whose kernel weight exceeds e^MS_SPARSE_SKIP; clustered embeddings -- what a trained
-# network produces -- sit near 1 / #clusters, unstructured ones near 1); "on" / "off" force it. The decision is a function
-# of the cloud alone, so results do not depend on which clouds share a batch.
+# network produces -- sit near 1 / #clusters, unstructured ones near 1); "on" / "off" force it. The probe is a function of the
+# cloud alone; the SCHEDULE also depends on the batch (one cloud per call, or a single structured cloud among unstructured ones,
+# runs the dense kernels: 40 work items cannot fill 256 CUs) -- rows then differ by the summation order, ms_set_variant pins it.
 MS_SPARSE = "auto"
-MS_SPARSE_SKIP = -30.0
+# Blocks whose kernel weights are all <= e^MS_SPARSE_SKIP are skipped. -27.04 = ln 2^-39: a weight below 2^-39 becomes 0 when
+# the split-fp16 kernels round 2^14 p to fp16 (round to nearest even: 2^-25 and below -> 0), in the dense kernel too -- the sparse
+# schedule then drops exactly what the dense one cannot represent (rounds 2 / 3 used -30: bit-identical rows on the bench's
+# embeddings, 3 % more first products).
+MS_SPARSE_SKIP = -27.04
 # Threshold of the density probe. Round 2 (planted sigma = 0.01 clusters: near fractions ~0.08) used 0.3. A TRAINED network's
 # embeddings are wider -- near fractions 0.17 .. 0.54 on the 64 bench clouds, the kernel still skips 52 % of the first and 61 % of
 # the second products -- and the block-sparse kernel beats the dense one on every one of them (3.9 ms per cloud in a 64-cloud launch

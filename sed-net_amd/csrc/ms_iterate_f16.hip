@@ -1710,6 +1710,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
             thr[rho] = v;
         }
     }
+    const float dead_below = 2.98023223876953125e-8f * 0.5f * __expf(-4.0f * F16S_DELTA / (b * b));
     h16x8 qh[8], ql[8];
     auto split_q = [&](int ks, const float* v) {
 #pragma unroll
@@ -1963,6 +1964,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
                 }
                 // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0): the second product of such a block adds exactly nothing
                 live = __builtin_amdgcn_ballot_w64(pmax > 2.98023223876953125e-8f) != 0ull;
+                // ... and a block whose largest weight is below 2^-25 e^(-4 delta / b^2) stays that way until the masks are remade:
+                // every query is within delta of where the masks were made, hence within 2 delta of where it is now; a chord
+                // (<= 2) then changes by <= 2 delta and the exponent -chord^2 / 2 b^2 by <= 4 delta / b^2. The wave drops the stage
+                // from its OWN mask: no first product for it in the sweeps that follow (exactly the blocks whose second product
+                // would be skipped anyway).
+                if (__builtin_amdgcn_ballot_w64(pmax > dead_below) == 0ull && lane == 0)
+                    wmask[wave][st >> 6] &= ~(1ull << (st & 63));
                 ++n_first;
             };
 

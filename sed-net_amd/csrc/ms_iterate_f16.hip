@@ -1871,7 +1871,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         }
         if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
         __syncthreads();
-        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s (s + 64 NW, .. in further passes)
+        ++n_remake;
+        }   // remake
+        // ---- (3) the workgroup's stage list, ascending: thread s owns stage s (s + 64 NW, .. in further passes). Made in EVERY
+        // sweep (two barriers): between mask rebuilds the waves take dead stages out of their masks (below), and a stage no
+        // wave needs any more leaves the list -- no copy, no barrier for it.
         ns = 0;
         for (int s0 = 0; s0 < nst; s0 += 64 * NW) {
             const int st = s0 + tid;
@@ -1898,12 +1902,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         }
         __syncthreads();
         ns = __builtin_amdgcn_readfirstlane(ns);
-        ++n_remake;
         if (item_stages != nullptr) {                     // counting launch: the length of the first list is all that is wanted
             if (tid == 0) item_stages[cloud * nbx + bx] = ns;
             return;
         }
-        }   // remake
         n_listed += ns;
 
         // ---- (4) the pipeline over the list

@@ -485,6 +485,27 @@ def test_every_form_of_the_block_sparse_kernel(T):
         ops.ms_set_weight_digits(2)
 
 
+def test_block_sparse_kernel_beyond_the_item_sorter(T):
+    """More clouds than ms_sparse_item_order_kernel ranks in one workgroup (4096): the persistent kernel then takes its items in
+    natural order from one counter -- same rows as the dense kernel within the usual tolerance, same bits as the same clouds in a
+    small batch (what an item computes does not depend on the queue it came from)."""
+    from sednet_hip import ops, synth
+    base = np.stack([synth.clustered_embedding(N=1024, d=128, n_clusters=4 + c, sigma=0.02, seed=40 + c)[0] for c in range(4)])
+    Xb = dev(T, base)
+    B = 4100
+    X = Xb[T.arange(B, device="cuda") % 4].contiguous()
+    bw = T.full((B,), 0.15, device="cuda")
+    got = ops.ms_iterate_sparse(X, bw, 3)
+    small = ops.ms_iterate_sparse(Xb, bw[:4].contiguous(), 3)
+    assert T.equal(got[:4], small) and T.equal(got[4096:4100], small) and T.equal(got[2000:2004], small)
+    try:
+        ops.ms_set_variant("f16")
+        dense = ops._ms_iterate_dense(Xb, bw[:4].contiguous(), 3)
+    finally:
+        ops.ms_set_variant("auto")
+    np.testing.assert_allclose(small.cpu().numpy(), dense.cpu().numpy(), atol=3e-6)
+
+
 def test_sparse_preparation_kernels_keep_the_invariants_the_skipping_rule_needs(T):
     """sed_ms_sparse_prepare_f32 (pivots, k-means step, super-groups, stable sort, tile references -- HIP kernels, no library
     calls): the order is a permutation, Xs are the rows in that order, every reference is a unit vector (or zero for an empty

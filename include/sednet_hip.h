@@ -165,7 +165,8 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
  * by summation order only) and run as PERSISTENT workgroups: a first launch builds every work item's first stage list and reports
  * its length; the items are then queued per XCD -- whole clouds, heaviest first, a cloud's items longest first -- and the resident
  * workgroups take items from their XCD's queue (then from the others') through atomic counters in the workspace. Clouds whose rows
- * are not unit vectors run the exact dense fp32 kernel. N <= 16 384; iters = 0 copies the rows. */
+ * are not unit vectors run the exact dense fp32 kernel. N <= 16 384; d = 128, or 160 (rows padded from the HPNet flow's 140
+ * columns; default form only); iters = 0 copies the rows. */
 int sed_ms_iterate_bounds_f16_refs(int N);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
 int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
@@ -176,7 +177,7 @@ int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* b
  * stride-th row, one k-means step, single-linkage super-groups of the means (merge_angle, radians), rows stable-sorted by
  * (super-group, group) -> order [B,N] (sorted position -> row), Xs [B,N,128] the rows in that order, and per 32-row tile two
  * references + cos(alpha) in the layout sed_ms_iterate_bounds_f16_f32 takes. Deterministic (integer atomics, sums in row order).
- * sed_unsort_rows_f32: out[b, order[b,i]] = in[b,i] -- the result back in the caller's row order. d = 128, N <= 16 384. */
+ * sed_unsort_rows_f32: out[b, order[b,i]] = in[b,i] -- the result back in the caller's row order. d = 128 or 160, N <= 16 384. */
 size_t sed_ms_sparse_prepare_workspace_bytes(int B, int N, int P);
 int sed_ms_sparse_prepare_f32(int B, int N, int d, int P, int stride, float merge_angle, const float* X, int* order, float* Xs,
                               float* tile_ref, float* tile_cosalpha, void* workspace, size_t workspace_bytes,

@@ -839,7 +839,7 @@ int ms_f16_launch(int B, int N, int d, int iters, const float* bw, const float* 
                   int** flags_out, int digits, int wq, hipStream_t stream);
 
 size_t ms_f16_sparse_workspace_bytes(int B, int N);
-int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream);
 
@@ -1010,16 +1010,21 @@ extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, con
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !tile_ref || !tile_cosalpha ||
         margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2 || form < 0 || form > 5)
         return SED_EINVAL;
-    if (d != 128) return SED_EUNSUPPORTED;
+    if (d != 128 && d != 160) return SED_EUNSUPPORTED;
     if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
     if (iters == 0) {                                       // zero iterations: the rows themselves
         const hipError_t e = hipMemcpyAsync(newX, X, (size_t)B * N * d * sizeof(float), hipMemcpyDeviceToDevice, stream);
         return e == hipSuccess ? SED_OK : (int)e;
     }
     int* flags = nullptr;
-    const int rc = ms_f16_sparse_launch(B, N, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
+    const int rc = ms_f16_sparse_launch(B, N, d, iters, bw, X, newX, workspace, &flags, skip_below, tile_ref, tile_cosalpha,
                                         margin, (unsigned long long*)stats, weight_digits == 1 ? 1 : 2, form, stream);
     if (rc != SED_OK) return rc;
+    if (d == 160) {                                         // flagged clouds: the exact fp32 kernel of that width
+        ms_iterate_kernel<5><<<dim3((N + 127) / 128, B), 256, 0, stream>>>(X, newX, bw, N, iters, flags);
+        SED_LAUNCH_CHECK();
+        return SED_OK;
+    }
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
     static bool attr_fb = false;
     if (!attr_fb) {

@@ -1037,7 +1037,6 @@ constexpr int F16S_REFGROUP = 12;                 // reference images per LDS lo
 #define F16S_DELTA_V 0.005f
 #endif
 constexpr float F16S_DELTA = F16S_DELTA_V;              // masks stay valid while no query has turned by more than this (rad)
-constexpr int F16S_REFBYTES = 9216;               // the first 9 DMA pieces of a stage image cover its 8704-byte head plane
 
 // ------------------------------------------------------------------------------------------------------------
 // Block-sparse schedule, round 3 form (ms_iterate_d128_f16x_kernel): the same skipping RULE as ms_iterate_d128_f16s_kernel below
@@ -1644,7 +1643,8 @@ __global__ __launch_bounds__(64 * NW, 1) void ms_iterate_d128_f16x_kernel(
 // six stage buffers instead of three), second-product operands by transpose reads like ms_iterate_f16w_kernel
 // NW: waves per workgroup: 8 (256 query rows, one workgroup per CU) or 4 (128 rows, two per CU: smaller unions of the waves' stage
 // lists, two independent barrier domains per CU, twice the stage copies)
-template <bool STAGGER, bool PL = true, bool RM = false, int NW = 8>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
+// NT: 32-feature tiles of a row: 4 (d = 128) or 5 (d = 160: the HPNet-widened embedding; row-major images only)
+template <bool STAGGER, bool PL = true, bool RM = false, int NW = 8, int NT = 4>     // PL = false: fp16 heads of the weights only (see ms_iterate_d128_f16q_kernel)
 __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
     const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
     const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
@@ -1652,12 +1652,16 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
     unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
     int* __restrict__ sched, int head0, int* __restrict__ item_stages) {
     using L = StageLayout<32>;
-    constexpr int XROW = L::XROW, TROW = L::TROW, STAGE = RM ? StageLayoutN::STAGE : L::STAGE, NPIECE = STAGE / 1024;
-    constexpr int OFF_XH = L::OFF_XH, OFF_XL = L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
-    static_assert(StageLayoutN::XROW == L::XROW && StageLayoutN::OFF_XL == L::OFF_XL, "the X planes of both layouts coincide");
+    using LR = StageLayoutD<NT>;
+    static_assert(RM || NT == 4, "four-plane images: d = 128 only");
+    constexpr int D = 32 * NT, KS = 2 * NT, NSTEP = 4 * NT;      // feature width, k-steps of the first product, operand steps of a block
+    constexpr int XROW = RM ? LR::XROW : L::XROW, TROW = L::TROW, STAGE = RM ? LR::STAGE : L::STAGE, NPIECE = STAGE / 1024;
+    constexpr int OFF_XH = 0, OFF_XL = RM ? LR::OFF_XL : L::OFF_XL, OFF_TH = L::OFF_TH, OFF_TL = L::OFF_TL;
+    static_assert(StageLayoutN::XROW == L::XROW && StageLayoutN::OFF_XL == L::OFF_XL, "the X planes of both d = 128 layouts coincide");
     constexpr int MAXW = F16S_MAXW;
-    constexpr int NBUF = RM ? (NW == 8 ? F16S_NBUF_RM : 4) : F16S_NBUF;
-    constexpr int REFG = NBUF * STAGE / F16S_REFBYTES < F16S_REFGROUP ? NBUF * STAGE / F16S_REFBYTES : F16S_REFGROUP;
+    constexpr int NBUF = RM ? (NW == 8 ? F16S_NBUF_RM : (NT == 4 ? 4 : 3)) : F16S_NBUF;
+    constexpr int REFP = (32 * XROW + 1023) / 1024, REFB = REFP * 1024;       // DMA pieces / bytes that cover an image's head plane
+    constexpr int REFG = NBUF * STAGE / REFB < F16S_REFGROUP ? NBUF * STAGE / REFB : F16S_REFGROUP;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE]
     __shared__ unsigned long long wmask[NW][MAXW];
     __shared__ int slist[512];
@@ -1683,7 +1687,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
     [&]() __attribute__((always_inline)) {
     if (flags[cloud]) return;
     if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
-    const float* Xc = X + (size_t)cloud * N * 128;
+    const float* Xc = X + (size_t)cloud * N * D;
     const int nst = (N + 31) >> 5;
     const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
     const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
@@ -1711,7 +1715,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         }
     }
     const float dead_below = 2.98023223876953125e-8f * 0.5f * __expf(-4.0f * F16S_DELTA / (b * b));
-    h16x8 qh[8], ql[8];
+    h16x8 qh[KS], ql[KS];
     auto split_q = [&](int ks, const float* v) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1724,25 +1728,25 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
     // rows come in: the row update needs no exchange); row-major images: features 16 ks + 8 hi + 0..7 (the image's own order: the
     // row update exchanges four values per k-step with the other lane half, like ms_iterate_f16w_kernel)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[8];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * 128 + 32 * c + (RM ? 16 * j + 8 * hi + 4 * g : 8 * (2 * j + g) + 4 * hi));
+                const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * D + 32 * c + (RM ? 16 * j + 8 * hi + 4 * g : 8 * (2 * j + g) + 4 * hi));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
             }
             split_q(2 * c + j, v);
         }
 
-    static_assert(NPIECE == (RM ? 17 : 37), "piece distribution below is written for 37 / 17 pieces");
+    static_assert(RM || NPIECE == 37, "the four-plane piece distribution below is written for 37 pieces");
     const unsigned lane16 = lane * 16;
     auto stage_dma = [&](int st, int buf) {
         const uint8_t* src = blob_c + (size_t)st * STAGE;
         uint8_t* dst = lds + buf * STAGE;
-        if constexpr (RM) {                               // 17 pieces dealt round-robin to the 8 waves
+        if constexpr (RM) {                               // 17 / 21 pieces dealt round-robin to the waves
 #pragma unroll
             for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
                 const int pc = wave + NW * i;
@@ -1780,23 +1784,23 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         return __builtin_bit_cast(h16x8, both);
     };
     auto ring_load = [&](int t, const uint8_t* base) {
-        if (t < 8) {
+        if (t < KS) {
             fa[t & 3] = *(const h16x8*)(base + OFF_XH + xoff + t * 32);
             fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
         } else if constexpr (RM) {
-            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
             fa[t & 3] = tr8(base + OFF_XH, c, j);
             fb[t & 3] = tr8(base + OFF_XL, c, j);
         } else {
-            const int c = (t - 8) >> 1, j = (t - 8) & 1;
+            const int c = (t - KS) >> 1, j = (t - KS) & 1;
             fa[t & 3] = *(const h16x8*)(base + OFF_TH + toff + c * 32 * TROW + j * 32);
             fb[t & 3] = *(const h16x8*)(base + OFF_TL + toff + c * 32 * TROW + j * 32);
         }
     };
 
-    f32x16 o[4];
+    f32x16 o[NT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float rsum = 0.f;
@@ -1818,9 +1822,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         }
         if (remake) {
         if (qrow < N) {                                  // remember where the masks were made: the row's slot of the output
-            float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+            float* keep = newX + ((size_t)cloud * N + qrow) * D;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NT; ++c)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -1837,21 +1841,21 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         for (int g0 = 0; g0 < nrs; g0 += REFG) {
             const int ng = min(REFG, nrs - g0);
             if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
-            for (int pc = wave; pc < ng * 9; pc += NW) {      // 1 KiB pieces: image pc / 9, piece pc % 9
-                const int im = pc / 9, piece = pc - 9 * im;
+            for (int pc = wave; pc < ng * REFP; pc += NW) {   // 1 KiB pieces: image pc / REFP, piece pc % REFP
+                const int im = pc / REFP, piece = pc - REFP * im;
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
-                    (__attribute__((address_space(3))) void*)(lds + im * F16S_REFBYTES + piece * 1024), 16, 0, 0);
+                    (__attribute__((address_space(3))) void*)(lds + im * REFB + piece * 1024), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             for (int im = 0; im < ng; ++im) {
-                const uint8_t* rbase = lds + im * F16S_REFBYTES + OFF_XH + xoff_nat;
+                const uint8_t* rbase = lds + im * REFB + OFF_XH + xoff_nat;
                 f32x16 sr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sr[r] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                for (int t = 0; t < KS; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
                 unsigned word = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1936,7 +1940,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < KS; ++t) {
                     s = mfma16(fb[t & 3], qh[t], s);
                     s = mfma16(fa[t & 3], ql[t], s);
                     s = mfma16(fa[t & 3], qh[t], s);
@@ -1986,13 +1990,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
             if (live) {
                 ++n_second;
 #pragma unroll
-                for (int t = 8; t < 16; ++t) {
-                    const int c = (t - 8) >> 1, jj = (t - 8) & 1;
+                for (int t = KS; t < NSTEP; ++t) {
+                    const int c = (t - KS) >> 1, jj = (t - KS) & 1;
                     o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
                     if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
                     o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
-                    if (t + 3 < 16) ring_load(t + 3, base);
-                    else if (j + 1 < ns) ring_load(t + 3 - 16, nbase);
+                    if (t + 3 < NSTEP) ring_load(t + 3, base);
+                    else if (j + 1 < ns) ring_load(t + 3 - NSTEP, nbase);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if (j + 1 < ns) {
@@ -2007,7 +2011,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         const float Dinv = UNSCALE_O / rs;
         float n2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NT; ++c) {
             float qacc[16];                               // the current row in accumulator order
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -2040,9 +2044,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         if (it + 1 < iters) {   // how far is the new row from where the masks were made (angle <= 1.06 chord for chords <= 0.6)
             float ch2 = 0.f;
             if (RM) {                                     // new Q operand (exchange with the other lane half) and its distance to the parked row
-                const float* kept = newX + ((size_t)cloud * N + qrow_c) * 128 + 8 * hi;
+                const float* kept = newX + ((size_t)cloud * N + qrow_c) * D + 8 * hi;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         float v[8];
@@ -2065,10 +2069,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
                     }
                 if (qrow >= N) ch2 = 0.f;
             } else if (qrow < N) {
-                const float* keep = newX + ((size_t)cloud * N + qrow) * 128;
+                const float* keep = newX + ((size_t)cloud * N + qrow) * D;
                 const float inv = 1.0f / nrm;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 k = *(const f32x4*)(keep + 32 * c + 8 * g + 4 * hi);
@@ -2087,9 +2091,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         }
         if (it == iters - 1) {
             if (qrow < N) {
-                float* out = newX + ((size_t)cloud * N + qrow) * 128;
+                float* out = newX + ((size_t)cloud * N + qrow) * D;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm,
@@ -2100,7 +2104,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
         } else {
             if (!RM) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < NT; ++c)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         float v[8];
@@ -2110,7 +2114,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void ms_iterate_d128_f16s_kernel(
                     }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NT; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
             rsum = 0.f;
@@ -2419,23 +2423,23 @@ static int f16x_launch(int B, int N, int iters, const float* bw, const float* X,
 #ifndef F16S_STAG
 #define F16S_STAG true
 #endif
-template <bool RM, int NW = 8>
+template <bool RM, int NW = 8, int NT = 4>
 static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
                        uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                        float margin, unsigned long long* stats, int digits, int* sched, hipStream_t stream) {
     using L = StageLayout<32>;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
-    constexpr int sm = RM ? (NW == 8 ? F16S_NBUF_RM : 4) * StageLayoutN::STAGE : F16S_NBUF * L::STAGE;
+    constexpr int sm = RM ? (NW == 8 ? F16S_NBUF_RM : (NT == 4 ? 4 : 3)) * StageLayoutD<NT>::STAGE : F16S_NBUF * L::STAGE;
     static_assert(RM || NW == 8, "four-plane images: 8-wave workgroups only (LDS)");
     hipError_t e = hipSuccess;
     static bool attr = false;
     if (!attr) {
         e = hipFuncSetAttribute((const void*)ms_split_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, L::STAGE);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW, NT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW>,
+        e = hipFuncSetAttribute((const void*)ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW, NT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
         attr = true;
@@ -2456,26 +2460,29 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
     const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
     e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    if (RM) {
+    if (RM && NT != 4) {
+        ms_split_d_kernel<NT><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_d_kernel<NT><<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    } else if (RM) {
         ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
         ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     } else {
         ms_split_kernel<32><<<dim3(nst, B), 256, L::STAGE, stream>>>(X, bw, blob, flags, N, nst);
         ms_split_kernel<32><<<dim3(nrs, B), 256, L::STAGE, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
     }
-    ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+    ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW, NT><<<grid, 64 * NW, sm, stream>>>(
         X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
         item_stages);
     if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched);
     if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
-        ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, false, RM, NW, NT><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
-        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW, NT><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
             listed ? 16 : 2, nullptr);
     } else
-        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW><<<grid, 64 * NW, sm, stream>>>(
+        ms_iterate_d128_f16s_kernel<F16S_STAG, true, RM, NW, NT><<<grid, 64 * NW, sm, stream>>>(
             X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
             listed ? 8 : 1, nullptr);
     SED_LAUNCH_CHECK();
@@ -2485,7 +2492,7 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
 // form: 1 = round 2's 8-wave kernel on four-plane images (ms_iterate_d128_f16s_kernel); 2 / 3 = the 64-queries-per-wave kernel on
 // row-major images with 2- / 4-wave workgroups (ms_iterate_d128_f16x_kernel); 4 = the 8-wave kernel on row-major images; 5 = the same with 4-wave workgroups; 0 = default
 constexpr int MS_SPARSE_DEFAULT_FORM = 5;
-int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, void* workspace,
+int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
@@ -2508,6 +2515,12 @@ int ms_f16_sparse_launch(int B, int N, int iters, const float* bw, const float* 
     if (form == 3)
         return f16x_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
                               stats, digits, sched, stream);
+    if (d == 160) {                                        // the HPNet-widened embedding: five feature tiles, default form only
+        if (form != 5) return SED_EUNSUPPORTED;
+        return f16s_launch<true, 4, 5>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha,
+                                       margin, stats, digits, sched, stream);
+    }
+    if (d != 128) return SED_EUNSUPPORTED;
     if (form == 5)
         return f16s_launch<true, 4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
                                     stats, digits, sched, stream);

@@ -13,16 +13,17 @@
 // walks all P steps in one launch (the host version: 5 launches per step). Candidates = every `stride`-th row.
 namespace {
 
+template <int D>                                              // row width: 128, or 160 (the HPNet-widened embedding)
 __global__ __launch_bounds__(1024) void fps_pivots_kernel(const float* __restrict__ X, int N, int stride, int P,
                                                           int* __restrict__ picks, float* __restrict__ picked) {
-    constexpr int D = 128, MAXC = 4096;
+    constexpr int MAXC = 4096, F = D / 8;                     // features per lane of a row's 8 lanes
     __shared__ float closest[MAXC];
     __shared__ __attribute__((aligned(16))) float pv[D];
     __shared__ float red_v[16];
     __shared__ int red_i[16];
     __shared__ int cur;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = tid >> 3, sub = tid & 7;                  // 8 lanes per candidate row, 16 features each
+    const int grp = tid >> 3, sub = tid & 7;                  // 8 lanes per candidate row, F = 16 / 20 features each
     const int cloud = blockIdx.x;
     const float* Xc = X + (size_t)cloud * N * D;
     const int Ns = (N + stride - 1) / stride;
@@ -37,16 +38,16 @@ __global__ __launch_bounds__(1024) void fps_pivots_kernel(const float* __restric
         }
         if (tid == 0) picks[(size_t)cloud * P + j] = c * stride;
         __syncthreads();
-        f32x4 p4[4];
+        f32x4 p4[F / 4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p4[u] = *(const f32x4*)(pv + 16 * sub + 4 * u);
+        for (int u = 0; u < F / 4; ++u) p4[u] = *(const f32x4*)(pv + F * sub + 4 * u);
         float best_v = 3.0e38f;
         int best_i = 0x7fffffff;
         for (int r = grp; r < Ns; r += 128) {
-            const float* row = Xc + (size_t)r * stride * D + 16 * sub;
+            const float* row = Xc + (size_t)r * stride * D + F * sub;
             float d = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < F / 4; ++u) {
                 const f32x4 x = *(const f32x4*)(row + 4 * u);
                 d = fmaf(x[0], p4[u][0], fmaf(x[1], p4[u][1], fmaf(x[2], p4[u][2], fmaf(x[3], p4[u][3], d))));
             }
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(1024) void fps_pivots_kernel(const float* __restric
 extern "C" int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, int* picks, float* picked,
                                   hipStream_t stream) {
     if (B <= 0 || N <= 0 || stride <= 0 || P <= 0 || !X || !picks || !picked) return SED_EINVAL;
-    if (d != 128 || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride) return SED_EUNSUPPORTED;
-    fps_pivots_kernel<<<B, 1024, 0, stream>>>(X, N, stride, P, picks, picked);
+    if ((d != 128 && d != 160) || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride) return SED_EUNSUPPORTED;
+    if (d == 160) fps_pivots_kernel<160><<<B, 1024, 0, stream>>>(X, N, stride, P, picks, picked);
+    else fps_pivots_kernel<128><<<B, 1024, 0, stream>>>(X, N, stride, P, picks, picked);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -100,12 +102,13 @@ extern "C" int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const 
 // cosine of the cap that holds its rows. Everything is deterministic: integer atomics only, sums in row order.
 namespace {
 
-constexpr int PREP_D = 128, PREP_P = 64;
+constexpr int PREP_P = 64;
 
 // rows -> index of the pivot with the largest dot product (ties: the lowest index), on the matrix pipe: scores [pivot][row] =
 // P X^T with both operands rounded to fp16 (|error| <= 1e-3 on a dot product of unit vectors -- it moves a row that is about
 // equally far from two pivots to the other one, and ANY grouping is a valid input of the steps that follow; same bits in every
 // run). Wave = 32 rows x 64 pivots (two 32 x 32 x 16 MFMA tiles over 8 k-steps), lane = one row, workgroup = 128 rows.
+template <int PREP_D>
 __global__ __launch_bounds__(256) void prep_assign_kernel(const float* __restrict__ X, const float* __restrict__ piv, int N, int P,
                                                           int* __restrict__ grp, int* __restrict__ counts) {
     __shared__ int hist[PREP_P];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void prep_assign_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < PREP_D / 16; ++ks) {
         const h16x8 xb = load8(Xc + (size_t)rc * PREP_D + 16 * ks + 8 * hi);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -168,21 +171,22 @@ __global__ __launch_bounds__(256) void prep_assign_kernel(const float* __restric
 //         F.normalize's eps);
 //   else: member i of the group written to position start[group] + i of the sorted order: row index, the row itself, and the
 //         group's super-group.
-template <bool MEAN>
-__global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __restrict__ X, const int* __restrict__ grp, int N, int P,
-                                                              float* __restrict__ piv, const int* __restrict__ start,
-                                                              const int* __restrict__ comp, int* __restrict__ order,
-                                                              float* __restrict__ Xs, int* __restrict__ scomp) {
+template <bool MEAN, int PREP_D>
+__global__ __launch_bounds__(4 * PREP_D) void prep_group_walk_kernel(const float* __restrict__ X, const int* __restrict__ grp, int N, int P,
+                                                                     float* __restrict__ piv, const int* __restrict__ start,
+                                                                     const int* __restrict__ comp, int* __restrict__ order,
+                                                                     float* __restrict__ Xs, int* __restrict__ scomp) {
+    constexpr int NTHR = 4 * PREP_D, NWV = NTHR / 64;            // 512 / 640 threads: 4 partial sums x one thread per feature
     __shared__ unsigned short members[16384];
-    __shared__ int wcnt[8];
+    __shared__ int wcnt[NWV];
     __shared__ float part[4][PREP_D];
-    __shared__ float red[2];
+    __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = blockIdx.x, cloud = blockIdx.y;
     const float* Xc = X + (size_t)cloud * N * PREP_D;
     const int* gc = grp + (size_t)cloud * N;
     int cnt = 0;
-    for (int r0 = 0; r0 < N; r0 += 512) {
+    for (int r0 = 0; r0 < N; r0 += NTHR) {
         const int r = r0 + tid;
         const bool in = r < N && gc[r] == p;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __res
         __syncthreads();
         int off = cnt;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < NWV; ++v) {
             const int c = wcnt[v];
             if (v < wave) off += c;
             cnt += c;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __res
         if (in) members[off + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)r;
         __syncthreads();
     }
-    const int q = tid >> 7, d = tid & 127;
+    const int q = tid / PREP_D, d = tid - q * PREP_D;
     if (MEAN) {
         float acc = 0.f;
         for (int i = q; i < cnt; i += 32) {                 // 8 rows in flight per thread, added in list order
@@ -210,16 +214,17 @@ __global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __res
         }
         part[q][d] = acc;
         __syncthreads();
-        if (tid < PREP_D) {
-            const float sum = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-            float s2 = sum * sum;
+        // (every thread takes part in the shuffles: threads past the row width carry zeros)
+        const float sum = tid < PREP_D ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.f;
+        float s2 = sum * sum;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
-            if (lane == 0) red[wave] = s2;
-            part[0][tid] = sum;
-        }
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+        __syncthreads();                                    // part[1 ..] have been read
+        if (lane == 0 && wave < 4) red[wave] = wave * 64 < PREP_D ? s2 : 0.f;
+        if (tid < PREP_D) part[0][tid] = sum;
         __syncthreads();
-        if (tid < PREP_D) piv[((size_t)cloud * P + p) * PREP_D + tid] = part[0][tid] / fmaxf(sqrtf(red[0] + red[1]), 1.0e-12f);
+        if (tid < PREP_D)
+            piv[((size_t)cloud * P + p) * PREP_D + tid] = part[0][tid] / fmaxf(sqrtf((red[0] + red[1]) + red[2]), 1.0e-12f);
     } else {
         const int pos0 = start[(size_t)cloud * P + p], sg = comp[(size_t)cloud * P + p];
         for (int i = q; i < cnt; i += 4) {
@@ -235,13 +240,14 @@ __global__ __launch_bounds__(512) void prep_group_walk_kernel(const float* __res
 
 // Per cloud: which means are within merge_angle of each other, the connected components of that graph (super-groups, named by
 // their smallest member), and where every group starts in the order sorted by (super-group, group). One wave; thread p = group p.
+template <int PREP_D>
 __global__ __launch_bounds__(64) void prep_components_kernel(const float* __restrict__ piv, const int* __restrict__ counts, int P,
                                                              float cos_merge, int* __restrict__ comp, int* __restrict__ start) {
     __shared__ float pv[PREP_P * (PREP_D + 1)];
     __shared__ int cc[PREP_P], cnt[PREP_P];
     const int p = threadIdx.x, cloud = blockIdx.x;
     const float* pc = piv + (size_t)cloud * P * PREP_D;
-    for (int i = p; i < P * PREP_D; i += 64) pv[(i >> 7) * (PREP_D + 1) + (i & 127)] = pc[i];
+    for (int i = p; i < P * PREP_D; i += 64) pv[(i / PREP_D) * (PREP_D + 1) + (i % PREP_D)] = pc[i];
     cc[p] = p;
     cnt[p] = p < P ? counts[(size_t)cloud * P + p] : 0;
     __syncthreads();
@@ -282,51 +288,59 @@ __global__ __launch_bounds__(64) void prep_components_kernel(const float* __rest
 // tile's first super-group and the rest -- a tile inside one super-group: its two halves -- each with the normalised sum of its
 // rows and the smallest dot product of a row with it (1 for an empty group). Tiles past the end of the cloud: zero rows,
 // cos alpha = 1. The last tile of a ragged cloud is filled up with copies of the last row. 128 threads per tile slot.
-__global__ __launch_bounds__(128) void prep_tile_refs_kernel(const float* __restrict__ Xs, const int* __restrict__ scomp, int N,
-                                                             int nref, float* __restrict__ ref, float* __restrict__ cosalpha) {
+template <int PREP_D>
+__global__ __launch_bounds__((PREP_D + 63) / 64 * 64) void prep_tile_refs_kernel(const float* __restrict__ Xs, const int* __restrict__ scomp,
+                                                                                  int N, int nref, float* __restrict__ ref,
+                                                                                  float* __restrict__ cosalpha) {
+    constexpr int NQ = PREP_D / 32;                          // 32-feature parts of a row
     __shared__ float xt[32 * (PREP_D + 1)];
     __shared__ float m[2][PREP_D];
-    __shared__ float part[4][32];
-    __shared__ float red[2][2];
+    __shared__ float part[NQ][32];
+    __shared__ float red[3][2];
     __shared__ int sc[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool mine = tid < PREP_D;                          // (the last wave of a 160-wide row is half empty: it carries zeros)
     const int t = blockIdx.x, cloud = blockIdx.y;
     const int ntile = (N + 31) >> 5;
     const int rho0 = ((t >> 5) * 2) * 32 + (t & 31), rho1 = rho0 + 32;
     float* r0p = ref + ((size_t)cloud * nref + rho0) * PREP_D;
     float* r1p = ref + ((size_t)cloud * nref + rho1) * PREP_D;
     if (t >= ntile) {
-        r0p[tid] = 0.f;
-        r1p[tid] = 0.f;
+        if (mine) { r0p[tid] = 0.f; r1p[tid] = 0.f; }
         if (tid == 0) { cosalpha[(size_t)cloud * nref + rho0] = 1.f; cosalpha[(size_t)cloud * nref + rho1] = 1.f; }
         return;
     }
     const float* Xc = Xs + (size_t)cloud * N * PREP_D;
     if (tid < 32) sc[tid] = scomp[(size_t)cloud * N + min(32 * t + tid, N - 1)];
-    for (int r = 0; r < 32; ++r) xt[r * (PREP_D + 1) + tid] = Xc[(size_t)min(32 * t + r, N - 1) * PREP_D + tid];
+    if (tid < 6) red[tid >> 1][tid & 1] = 0.f;
+    if (mine)
+        for (int r = 0; r < 32; ++r) xt[r * (PREP_D + 1) + tid] = Xc[(size_t)min(32 * t + r, N - 1) * PREP_D + tid];
     __syncthreads();
     bool pure = true;
     for (int r = 1; r < 32; ++r) pure = pure && sc[r] == sc[0];
     auto in_a = [&](int r) { return pure ? r < 16 : sc[r] == sc[0]; };
     float sa = 0.f, sb = 0.f;
-    for (int r = 0; r < 32; ++r) {
-        const float v = xt[r * (PREP_D + 1) + tid];
-        if (in_a(r)) sa += v;
-        else sb += v;
-    }
+    if (mine)
+        for (int r = 0; r < 32; ++r) {
+            const float v = xt[r * (PREP_D + 1) + tid];
+            if (in_a(r)) sa += v;
+            else sb += v;
+        }
     float qa = sa * sa, qb = sb * sb;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { qa += __shfl_xor(qa, off, 64); qb += __shfl_xor(qb, off, 64); }
     if (lane == 0) { red[wave][0] = qa; red[wave][1] = qb; }
     __syncthreads();
-    const float ma = sa / fmaxf(sqrtf(red[0][0] + red[1][0]), 1.0e-12f);
-    const float mb = sb / fmaxf(sqrtf(red[0][1] + red[1][1]), 1.0e-12f);
-    m[0][tid] = ma;
-    m[1][tid] = mb;
-    r0p[tid] = ma;
-    r1p[tid] = mb;
+    const float ma = sa / fmaxf(sqrtf((red[0][0] + red[1][0]) + red[2][0]), 1.0e-12f);
+    const float mb = sb / fmaxf(sqrtf((red[0][1] + red[1][1]) + red[2][1]), 1.0e-12f);
+    if (mine) {
+        m[0][tid] = ma;
+        m[1][tid] = mb;
+        r0p[tid] = ma;
+        r1p[tid] = mb;
+    }
     __syncthreads();
-    {   // dot of row r with its own group's reference: 4 threads per row, 32 features each
+    if (mine) {   // dot of row r with its own group's reference: NQ threads per row, 32 features each
         const int r = tid & 31, q = tid >> 5;
         const float* mm = m[in_a(r) ? 0 : 1];
         float d = 0.f;
@@ -335,7 +349,9 @@ __global__ __launch_bounds__(128) void prep_tile_refs_kernel(const float* __rest
     }
     __syncthreads();
     if (tid < 32) {
-        const float d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        float d = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+#pragma unroll
+        for (int q = 4; q < NQ; ++q) d += part[q][tid];
         float da = in_a(tid) ? d : 1.f, db = in_a(tid) ? 1.f : d;
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) { da = fminf(da, __shfl_xor(da, off, 64)); db = fminf(db, __shfl_xor(db, off, 64)); }
@@ -343,14 +359,18 @@ __global__ __launch_bounds__(128) void prep_tile_refs_kernel(const float* __rest
     }
 }
 
-// out[order[i]] = in[i] (rows of 128 floats): the result of the block-sparse pass back in the caller's row order
+// out[order[i]] = in[i] (rows of PREP_D floats): the result of the block-sparse pass back in the caller's row order
+template <int PREP_D>
 __global__ __launch_bounds__(256) void unsort_rows_kernel(const float* __restrict__ in, const int* __restrict__ order,
                                                           float* __restrict__ out, size_t rows, int N) {
-    const size_t i = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    constexpr int TPR = PREP_D / 4, RPB = 256 / TPR;         // threads per row (one float4 each), rows per workgroup
+    if (threadIdx.x >= RPB * TPR) return;
+    const size_t i = (size_t)blockIdx.x * RPB + threadIdx.x / TPR;
     if (i >= rows) return;
+    const int l4 = threadIdx.x % TPR;
     const size_t cloud = i / N;
     const int dst = order[i];
-    *(f32x4*)(out + (cloud * N + dst) * PREP_D + 4 * (threadIdx.x & 31)) = *(const f32x4*)(in + i * PREP_D + 4 * (threadIdx.x & 31));
+    *(f32x4*)(out + (cloud * N + dst) * PREP_D + 4 * l4) = *(const f32x4*)(in + i * PREP_D + 4 * l4);
 }
 
 struct PrepCarve {
@@ -358,7 +378,7 @@ struct PrepCarve {
     float *picked, *piv;
     size_t bytes;
 };
-static PrepCarve prep_carve(void* ws, int B, int N, int P) {
+static PrepCarve prep_carve(void* ws, int B, int N, int P, int PREP_D = 160) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     uint8_t* b = (uint8_t*)ws;
     PrepCarve c;
@@ -379,42 +399,52 @@ static PrepCarve prep_carve(void* ws, int B, int N, int P) {
 
 extern "C" size_t sed_ms_sparse_prepare_workspace_bytes(int B, int N, int P) {
     if (B <= 0 || N <= 0 || P <= 0) return 0;
-    return prep_carve(nullptr, B, N, P).bytes;
+    return prep_carve(nullptr, B, N, P).bytes;                // (sized for the widest rows, d = 160)
 }
 
-// X [B,N,128] unit rows -> order [B,N] (sorted position -> row), Xs [B,N,128] = the rows in that order, tile_ref [B,nref,128] and
-// tile_cosalpha [B,nref] as sed_ms_iterate_bounds_f16_f32 takes them (nref = sed_ms_iterate_bounds_f16_refs(N)). P <= 64 pivots
-// among every stride-th row (at most 4096 candidates), merge_angle in radians.
+namespace {
+template <int D>
+int prep_run(int B, int N, int P, int stride, float merge_angle, const float* X, int* order, float* Xs, float* tile_ref,
+             float* tile_cosalpha, const PrepCarve& c, hipStream_t stream) {
+    const int nst = (N + 31) / 32, nref = 2 * ((nst + 31) / 32) * 32;
+    hipError_t e = hipMemsetAsync(c.counts, 0, (size_t)B * P * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    fps_pivots_kernel<D><<<B, 1024, 0, stream>>>(X, N, stride, P, c.picks, c.picked);
+    const dim3 ga((N + 127) / 128, B), gw(P, B);
+    prep_assign_kernel<D><<<ga, 256, 0, stream>>>(X, c.picked, N, P, c.grp, nullptr);
+    prep_group_walk_kernel<true, D><<<gw, 4 * D, 0, stream>>>(X, c.grp, N, P, c.piv, nullptr, nullptr, nullptr, nullptr, nullptr);
+    prep_assign_kernel<D><<<ga, 256, 0, stream>>>(X, c.piv, N, P, c.grp, c.counts);
+    prep_components_kernel<D><<<B, 64, 0, stream>>>(c.piv, c.counts, P, cosf(merge_angle), c.comp, c.start);
+    prep_group_walk_kernel<false, D><<<gw, 4 * D, 0, stream>>>(X, c.grp, N, P, nullptr, c.start, c.comp, order, Xs, c.scomp);
+    prep_tile_refs_kernel<D><<<dim3(nref / 2, B), (D + 63) / 64 * 64, 0, stream>>>(Xs, c.scomp, N, nref, tile_ref, tile_cosalpha);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+}  // namespace
+
+// X [B,N,d] unit rows (d = 128 or 160) -> order [B,N] (sorted position -> row), Xs [B,N,d] = the rows in that order, tile_ref
+// [B,nref,d] and tile_cosalpha [B,nref] as sed_ms_iterate_bounds_f16_f32 takes them (nref = sed_ms_iterate_bounds_f16_refs(N)).
+// P <= 64 pivots among every stride-th row (at most 4096 candidates), merge_angle in radians.
 extern "C" int sed_ms_sparse_prepare_f32(int B, int N, int d, int P, int stride, float merge_angle, const float* X, int* order,
                                          float* Xs, float* tile_ref, float* tile_cosalpha, void* workspace,
                                          size_t workspace_bytes, hipStream_t stream) {
     if (B <= 0 || N <= 0 || P <= 0 || stride <= 0 || !X || !order || !Xs || !tile_ref || !tile_cosalpha || !workspace ||
         !(merge_angle >= 0.f))
         return SED_EINVAL;
-    if (d != PREP_D || P > PREP_P || N > 16384 || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride)
+    if ((d != 128 && d != 160) || P > PREP_P || N > 16384 || (N + stride - 1) / stride > 4096 || P > (N + stride - 1) / stride)
         return SED_EUNSUPPORTED;
     const PrepCarve c = prep_carve(workspace, B, N, P);
     if (workspace_bytes < c.bytes) return SED_EINVAL;
-    const int nst = (N + 31) / 32, nref = 2 * ((nst + 31) / 32) * 32;
-    hipError_t e = hipMemsetAsync(c.counts, 0, (size_t)B * P * sizeof(int), stream);
-    if (e != hipSuccess) return (int)e;
-    fps_pivots_kernel<<<B, 1024, 0, stream>>>(X, N, stride, P, c.picks, c.picked);
-    const dim3 ga((N + 127) / 128, B), gw(P, B);
-    prep_assign_kernel<<<ga, 256, 0, stream>>>(X, c.picked, N, P, c.grp, nullptr);
-    prep_group_walk_kernel<true><<<gw, 512, 0, stream>>>(X, c.grp, N, P, c.piv, nullptr, nullptr, nullptr, nullptr, nullptr);
-    prep_assign_kernel<<<ga, 256, 0, stream>>>(X, c.piv, N, P, c.grp, c.counts);
-    prep_components_kernel<<<B, 64, 0, stream>>>(c.piv, c.counts, P, cosf(merge_angle), c.comp, c.start);
-    prep_group_walk_kernel<false><<<gw, 512, 0, stream>>>(X, c.grp, N, P, nullptr, c.start, c.comp, order, Xs, c.scomp);
-    prep_tile_refs_kernel<<<dim3(nref / 2, B), 128, 0, stream>>>(Xs, c.scomp, N, nref, tile_ref, tile_cosalpha);
-    SED_LAUNCH_CHECK();
-    return SED_OK;
+    return d == 160 ? prep_run<160>(B, N, P, stride, merge_angle, X, order, Xs, tile_ref, tile_cosalpha, c, stream)
+                    : prep_run<128>(B, N, P, stride, merge_angle, X, order, Xs, tile_ref, tile_cosalpha, c, stream);
 }
 
 extern "C" int sed_unsort_rows_f32(int B, int N, int d, const float* in, const int* order, float* out, hipStream_t stream) {
     if (B <= 0 || N <= 0 || !in || !order || !out) return SED_EINVAL;
-    if (d != PREP_D) return SED_EUNSUPPORTED;
+    if (d != 128 && d != 160) return SED_EUNSUPPORTED;
     const size_t rows = (size_t)B * N;
-    unsort_rows_kernel<<<(unsigned)((rows + 7) / 8), 256, 0, stream>>>(in, order, out, rows, N);
+    if (d == 160) unsort_rows_kernel<160><<<(unsigned)((rows + 5) / 6), 256, 0, stream>>>(in, order, out, rows, N);
+    else unsort_rows_kernel<128><<<(unsigned)((rows + 7) / 8), 256, 0, stream>>>(in, order, out, rows, N);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

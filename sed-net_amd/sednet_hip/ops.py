@@ -309,8 +309,8 @@ def ms_sparse_prepare(X, n_pivots=64, merge_angle=0.6):
     normalised group means with the smallest dot product of a row of each group with its mean.
     -> dict(order [B,N] int32: sorted position -> row, Xs [B,N,D], ref [B,nref,D], cosalpha [B,nref])."""
     B, N, D = X.shape
-    if N > 16384 or D != 128:
-        raise RuntimeError("block-sparse mean-shift schedule: d = 128 and N <= 16384 only")
+    if N > 16384 or D not in (128, 160):
+        raise RuntimeError("block-sparse mean-shift schedule: d = 128 / 160 and N <= 16384 only")
     P = min(n_pivots, 64, N)
     # (pivots picked among every `stride`-th row: the greedy loop is P dependent passes over the rows it looks at, and a
     # quarter of a 10 000-point cloud still holds a dozen rows of a cluster of 0.5 % of the points)
@@ -361,7 +361,7 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, margin=2e-3, 
     """ms_iterate with the block-sparse schedule: rows are sorted by nearest pivot, 32 x 32 blocks whose kernel weights
     are all <= e^skip_below are skipped (row sums change by <= N e^skip_below relative), the result is returned in the
     caller's row order. Products on the fp16 matrix pipe, bounds from the exact angle of every query to every tile's two
-    group means (sed_ms_iterate_bounds_f16_f32). d = 128 only. stats: optional int64 [5] device tensor the kernel adds its
+    group means (sed_ms_iterate_bounds_f16_f32). d = 128 / 160 (the HPNet-widened embedding, default form only). stats: optional int64 [5] device tensor the kernel adds its
     visit counts to."""
     return ms_sparse_run(ms_sparse_prepare(X, n_pivots), bw, iters, skip_below, margin, stats)
 
@@ -369,7 +369,7 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, margin=2e-3, 
 def ms_iterate(X, bw, iters):
     """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79)."""
     B, N, D = X.shape
-    if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D == 128 and iters > 0 and 1024 <= N <= 16384:
+    if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D in (128, 160) and iters > 0 and 1024 <= N <= 16384:
         if MS_SPARSE == "on":
             return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
         if B == 1:

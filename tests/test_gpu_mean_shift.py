@@ -485,6 +485,44 @@ def test_every_form_of_the_block_sparse_kernel(T):
         ops.ms_set_weight_digits(2)
 
 
+def test_block_sparse_kernel_at_the_hpnet_width(T):
+    """d = 160 (the HPNet flow's 140 columns, padded): preparation kernels and the block-sparse kernel instantiated for five feature
+    tiles -- rows within the dense d = 160 kernel's tolerance, zero pad columns stay zero, blocks are skipped on clustered rows, a
+    non-unit cloud falls back to the exact fp32 kernel of that width, non-default forms are refused."""
+    from sednet_hip import ops, synth
+    from sednet_hip._lib import lib, ptr, stream
+    Xs = np.stack([synth.clustered_embedding(N=4000, d=140, n_clusters=8 + c, sigma=0.006, seed=800 + c)[0] for c in range(3)])
+    Xs[2] *= np.float32(1.2)
+    X = ops.pad_features(dev(T, Xs))
+    assert X.shape[2] == 160
+    bw = T.full((3,), 0.1, device="cuda")
+    try:
+        ops.ms_set_variant("f16")
+        dense = ops._ms_iterate_dense(X, bw, 10)
+        ops.ms_set_variant("batched")
+        exact = ops._ms_iterate_dense(X, bw, 10)
+    finally:
+        ops.ms_set_variant("auto")
+    st = T.zeros(5, dtype=T.int64, device="cuda")
+    got = ops.ms_iterate_sparse(X, bw, 10, stats=st)
+    np.testing.assert_allclose(got[:2].cpu().numpy(), dense[:2].cpu().numpy(), atol=4e-6)
+    np.testing.assert_allclose(got[2].cpu().numpy(), exact[2].cpu().numpy(), atol=2e-5)
+    assert (got[:, :, 140:] == 0).all()
+    c = st.cpu().numpy()
+    assert 0 < c[2] <= c[1] < 0.6 * c[3]
+    assert T.equal(got, ops.ms_iterate_sparse(X, bw, 10))
+    prep = ops.ms_sparse_prepare(X)
+    order = prep["order"].long()
+    assert (T.sort(order, 1)[0] == T.arange(4000, device="cuda")[None]).all()
+    assert T.equal(prep["Xs"], T.gather(X, 1, order.unsqueeze(-1).expand(-1, -1, 160)))
+    try:
+        ops.MS_SPARSE_FORM = 4
+        with pytest.raises(RuntimeError):
+            ops.ms_iterate_sparse(X, bw, 2)
+    finally:
+        ops.MS_SPARSE_FORM = 0
+
+
 def test_block_sparse_kernel_beyond_the_item_sorter(T):
     """More clouds than ms_sparse_item_order_kernel ranks in one workgroup (4096): the persistent kernel then takes its items in
     natural order from one counter -- same rows as the dense kernel within the usual tolerance, same bits as the same clouds in a

@@ -168,7 +168,7 @@ def roofline_block(timers, N, iterations, digits, counters=None):
     split = sparse or all(m.get("schedule") == "split-fp16" for _, m in it)
     mpp = mfma_per_product(digits)
     peak = F16_MFMA_PEAK_TFLOPS / mpp if split else FP32_MFMA_PEAK_TFLOPS
-    blk = {"kernel": ("ms_iterate_d128_f16s_kernel<true, %s, true, 4>" % ("true" if digits == 2 else "false")) if sparse else
+    blk = {"kernel": ("ms_iterate_d128_f16s_kernel<true, %s, true, 4, %d>" % ("true" if digits == 2 else "false", D // 32)) if sparse else
                      (("ms_iterate_f16w_kernel<%d, %s, %s>" % (D // 32, "true" if D == 160 else "false", "true" if digits == 2 else "false")) if split
                       else "ms_iterate_d128_kernel"),
            "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),

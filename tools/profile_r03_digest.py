@@ -104,5 +104,10 @@ for n, flag in (("train", ""), ("train_bf16", " --bf16")):
             f"`{tr}` (under the profiler; 2 warm-up + 3 timed steps)."))
 d = last_json(os.path.join(O, "bench_default.out"))
 if d:
+    # (that run read the traffic record committed BEFORE this profile; the stored line carries the record of this one)
+    if d["roofline"]["kernel"].split("<")[0] == rec["kernel"].split("<")[0] and int(d["roofline"]["clouds_per_launch"]) == rec["clouds"]:
+        d["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        d["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md) of "
+                                           f"`{rec['command']}` at commit {rec['commit']}, {rec['date']}; a profile record, not re-measured inside this run")
     json.dump(d, open(os.path.join(P, "r03_bench_line.json"), "w"), indent=1)
 print("written:", sorted(x for x in os.listdir(P) if x.startswith("r03")))

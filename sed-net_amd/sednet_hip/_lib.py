@@ -78,7 +78,10 @@ SIGNATURES = {
     "sed_edgeconv_bwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P,
                                      c_int, P, c_size_t, P, P, P, c_size_t, c_int, P]),
     "sed_pair_entropy_partials": (c_size_t, [c_int]),
-    "sed_pair_entropy_f32": (c_int, [c_int, c_int, P, c_int, c_int, c_float, P, P]),
+    "sed_pair_entropy_f32": (c_int, [c_int, c_int, P, c_int, c_int, c_float, P, P, P]),
+    "sed_pair_entropy_split_bytes": (c_size_t, [c_int]),
+    "sed_pair_entropy_split_f32": (c_int, [c_int, c_int, P, c_int, P, P]),
+    "sed_pair_entropy_mfma_f32": (c_int, [c_int, P, c_int, c_float, P, P, P]),
     "sed_pointwise_partials_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_colext_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sed_pointwise_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),

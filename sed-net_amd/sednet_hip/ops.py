@@ -763,10 +763,38 @@ def segment_type_vote(labels, types, S, C=6):
 # HPNet entropy weights
 # ---------------------------------------------------------------------------------------------------
 
-def pair_entropy_sum(u, mode, alpha=0.0):
-    """u [M,K] contiguous -> fp64 scalar tensor: sum over ordered pairs of ||u_i - u_j|| (mode 0) or of
-    H(exp(-alpha ||u_i - u_j||)) (mode 1); see pair_entropy.hip."""
+PAIR_ENTROPY_MFMA = True      # K = 128: split-fp16 MFMA dot products instead of explicit differences on the vector ALUs
+
+
+def pair_entropy_split(u):
+    """CENTRED rows u [M,128] -> the operand buffer of the matrix-pipe entropy kernel (fp16 digits + fp32 norms)"""
     M, K = u.shape
-    part = torch.empty((lib.sed_pair_entropy_partials(M),), dtype=torch.float64, device=u.device)
-    check(lib.sed_pair_entropy_f32(M, K, ptr(u), u.stride(0), mode, float(alpha), ptr(part), stream()), "pair_entropy")
-    return part.sum()
+    buf = torch.empty((lib.sed_pair_entropy_split_bytes(M),), dtype=torch.uint8, device=u.device)
+    check(lib.sed_pair_entropy_split_f32(M, K, ptr(u), u.stride(0), ptr(buf), stream()), "pair_entropy_split")
+    return buf
+
+
+def pair_entropy_partials(u, mode, alpha=0.0, alpha_dev=None, out=None, split=None):
+    """u [M,K] contiguous -> fp64 partial sums [sed_pair_entropy_partials(M)] of ||u_i - u_j|| (mode 0) or of
+    H(exp(-alpha ||u_i - u_j||)) (mode 1) over all ordered pairs; see pair_entropy.hip. alpha_dev: a one-element device tensor
+    read by the kernel instead of `alpha`. split: pair_entropy_split(centred u) -> the K = 128 matrix-pipe kernel."""
+    M, K = u.shape
+    part = torch.empty((lib.sed_pair_entropy_partials(M),), dtype=torch.float64, device=u.device) if out is None else out
+    ad = ptr(alpha_dev) if alpha_dev is not None else None
+    if split is not None:
+        check(lib.sed_pair_entropy_mfma_f32(M, ptr(split), mode, float(alpha), ad, ptr(part), stream()), "pair_entropy_mfma")
+    else:
+        check(lib.sed_pair_entropy_f32(M, K, ptr(u), u.stride(0), mode, float(alpha), ad, ptr(part), stream()), "pair_entropy")
+    return part
+
+
+def pair_entropy_uses_mfma(u):
+    return PAIR_ENTROPY_MFMA and u.shape[-1] == 128
+
+
+def pair_entropy_sum(u, mode, alpha=0.0):
+    """-> fp64 scalar tensor: the sum over ordered pairs (pair_entropy_partials)"""
+    if pair_entropy_uses_mfma(u):
+        uc = (u - u.mean(0, keepdim=True)).contiguous()      # distances unchanged; no cancellation in |a|^2 + |b|^2 - 2 a.b
+        return pair_entropy_partials(uc, mode, alpha, split=pair_entropy_split(uc)).sum()
+    return pair_entropy_partials(u, mode, alpha).sum()

@@ -149,6 +149,33 @@ def compute_entropy(features, CHUNK=2000):
     return (ops.pair_entropy_sum(u, 1, alpha) / (N * N)).float()
 
 
+def compute_entropy_batch(features, CHUNK=2000):
+    """compute_entropy for every cloud of features [B,N,K] -> fp64 tensor [B] on the device, without a host round trip: the
+    interval / centring reductions run once over the batch, the first pass's average distance stays on the device and the second
+    pass's kernels read alpha from there. Same terms per cloud as compute_entropy."""
+    from sednet_hip import ops
+    if not features.is_cuda:
+        raise RuntimeError("compute_entropy runs on the HIP path: pass device tensors")
+    B, N, K = features.shape
+    sub = features[:, :ITER * CHUNK].float()
+    interval = 2 * (sub.amax(1) - sub.amin(1))                       # [B,K]
+    u = sub / interval[:, None, :]
+    mfma = ops.pair_entropy_uses_mfma(u)
+    if mfma:
+        u = u - u.mean(1, keepdim=True)
+    u = u.contiguous()
+    M = u.shape[1]
+    npart = ops.lib.sed_pair_entropy_partials(M)
+    part = torch.empty((B, npart), dtype=torch.float64, device=u.device)
+    splits = [ops.pair_entropy_split(u[b]) if mfma else None for b in range(B)]
+    for b in range(B):
+        ops.pair_entropy_partials(u[b], 0, out=part[b], split=splits[b])
+    alpha = (-np.log(0.5) / (part.sum(1) / (N * N))).float().contiguous()      # [B], device
+    for b in range(B):
+        ops.pair_entropy_partials(u[b], 1, alpha_dev=alpha[b:b + 1], out=part[b], split=splits[b])
+    return (part.sum(1) / (N * N)).float().double()
+
+
 def hpnet_process(affinity_feat, inputs_xyz, normals, id=None, types=None, edges=None, normal_smooth_w=0.5, CHUNK=2000,
                   gpu="cuda:0", drop_rest_idx=None, cache_dir=None, dense=False):
     """:157-233. affinity_feat [B,N,K] (not normalised), inputs_xyz / normals [B,N,3] -> [B,N,K+12(+8)].
@@ -160,6 +187,19 @@ def hpnet_process(affinity_feat, inputs_xyz, normals, id=None, types=None, edges
     V = None
     if not dense and (cache_dir is None or id is None):
         V = lobpcg_sparse(sparse_affinity(inputs_xyz, normals, sigma=normal_sigma, knn=edge_knn), k=edge_topk, niter=10)[1]
+        if drop_rest_idx is None:
+            # batched route (the pipeline's): every entropy of every cloud without a host round trip, one concatenation
+            v = V / (torch.norm(V, dim=-1, keepdim=True) + 1e-16)
+            specs = [affinity_feat, v]
+            weights = [1.7 - compute_entropy_batch(affinity_feat, CHUNK), normal_smooth_w - compute_entropy_batch(v, CHUNK)]
+            if types is not None:
+                t = torch.exp(types)
+                if edges is not None:
+                    t = torch.cat((t, torch.softmax(edges, dim=-1)), dim=-1)
+                specs.append(t)
+                weights.append(0.25 - compute_entropy_batch(t, CHUNK))
+            # (the reference multiplies by python floats: double arithmetic, rounded to fp32 at the product)
+            return torch.cat([s_ * w.float()[:, None, None] for s_, w in zip(specs, weights)], dim=-1)
     for b in range(affinity_feat.shape[0]):
         feat = affinity_feat[b:b + 1]
         weight_ent = [1.7 - float(compute_entropy(feat, CHUNK=CHUNK))]

@@ -145,8 +145,10 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
                        sed_stream_t stream);
 /* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel): identical
  * arithmetic, except that 32 x 32 (keys x queries) blocks in which every kernel weight is provably <= e^skip_below are skipped;
- * with skip_below = -30 every dropped weight is <= 9.4e-14, so a row sum (>= 1, the self weight) changes by <= N e^-30
- * relative: <= 1e-9 at N = 10 000, 60 x below fp32 resolution. X: unit rows sorted so that 32-row tiles are cluster-pure (any
+ * a row sum (>= 1, the self weight) changes by <= N e^skip_below relative. The Python mirror passes skip_below = -27.04 = ln 2^-39:
+ * a weight below 2^-39 rounds to zero when the split-fp16 kernels convert 2^14 p to fp16 -- in the dense kernel too --, so that
+ * value drops exactly what the dense kernel cannot represent (N 2^-39 = 1.8e-8 at N = 10 000). Between mask rebuilds a wave also
+ * leaves out the first product of a block all of whose weights are provably below that point until the next rebuild. X: unit rows sorted so that 32-row tiles are cluster-pure (any
  * order is correct; the order decides how much is skipped). Every tile t
  * has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
  * split) -- stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128], nref = sed_ms_iterate_bounds_f16_refs(N),

@@ -1,0 +1,128 @@
+// Shared pieces of the split-fp16 mean-shift kernels (ms_iterate_f16.hip: dense schedules, ms_sparse_f16.hip: block-sparse
+// schedule): operand types, scales, the row-major stage image and the kernels that lay X out as stage images.
+//
+// Arithmetic (same mathematics as ms_iterate.hip, /root/reference/src/mean_shift.py:56-77, guard.py:7-9): the two fp32 products
+// S = Q X^T and O = P X run on v_mfma_f32_32x32x16_f16 (16 x the rate of v_mfma_f32_32x32x2_f32). Every fp32 operand v is split
+// (round to nearest) into
+//     v * 2^s = h + l + e,   h = fp16(v 2^s),  l = fp16(v 2^s - h),  |e| <= 2^-24 |v 2^s|      (two 11-bit signed digits)
+// and a product a.b is evaluated as l_a h_b + h_a l_b + h_a h_b: three fp16 MFMAs (products of two fp16 values are exact in
+// fp32, accumulation is the MFMA's fp32 accumulator). What is dropped -- l_a l_b and the e terms -- is <= 3 * 2^-24 relative to
+// |a||b| per product, the size of ONE fp32 rounding, whereas the fp32 fma chain it replaces rounds 128 (S) / 10 000 (O) times.
+// Scales: X and Q by 2^11 (unit rows: |h| <= 2048, l stays a normal fp16 number for |x| >= 2^-14), P by 2^14 (weights <= 1;
+// anything below 2^-39 rounds to 0: a relative change of a row sum (>= 1, the self weight) of <= N 2^-39). p 2^14 <= 65504 needs
+// rows of norm <= 1: the split kernels measure the row norms and flag clouds that violate (|x|^2 - 1) / b^2 <= 1; flagged
+// clouds are skipped by the split-fp16 kernels and done by the exact fp32 kernel.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float SCALE_X = 2048.0f;               // 2^11
+constexpr float LOG2_SCALE_P = 14.0f;            // P is produced as 2^14 p
+constexpr float UNSCALE_Q = 1.0f / 2048.0f;
+constexpr float UNSCALE_O = 1.0f / 2048.0f;      // O carries 2^11 (X) * 2^14 (P); the row sum carries 2^14
+
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// Row-major stage image of 32 keys x NT * 32 features: the h plane then the l plane of X [key][feature], rows padded by 16 B
+// (conflict-free ds_read_b128 / ds_read_b64_tr_b16). X is fixed over the 50 iterations, so it is laid out ONCE per call; a stage is
+// copied to LDS by LDS-DMA (global_load_lds_dwordx4: linear copy in 1 KiB pieces, no staging registers). The first product reads
+// its A operand (8 features of one key per lane) with ds_read_b128, the second product (8 keys of one feature per lane) from the
+// SAME planes through gfx950's transpose read. NT = 4 (d = 128, the SED-Net embedding): 17 408 B; NT = 5 (d = 160: the 140
+// columns of the HPNet-widened embedding, generate_predictions_aug.py:371-377, zero padded): 21 504 B.
+template <int NT>
+struct StageLayoutD {
+    static constexpr int D = 32 * NT, XROW = 2 * D + 16, XPLANE = 32 * XROW, OFF_XH = 0, OFF_XL = XPLANE, STAGE = 2 * XPLANE;
+    static_assert(STAGE % 1024 == 0, "whole DMA pieces");
+};
+using StageLayoutN = StageLayoutD<4>;
+// accumulator row m = 16 a + 4 b + c  <->  image row sigma(m) = 16 a + 4 c + b (a 4 x 4 transpose inside every group of 16 rows):
+// the key order in which the first product must read the image rows so that its accumulator rows line up with the transpose
+// read's key order in the second product
+__host__ __device__ constexpr int sigma_row(int m) { return 16 * (m >> 4) + 4 * (m & 3) + ((m >> 2) & 3); }
+
+// X [B, N, 128] fp32 -> row-major stage images [B, nst, 17408] (h plane | l plane, rows = keys in natural order, 272 B apart)
+__global__ __launch_bounds__(256) void ms_split_n_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                         uint8_t* __restrict__ blob, int* __restrict__ flags, int N,
+                                                         int nst) {
+    using L = StageLayoutN;
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * 128;
+    uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
+    float n2max = 0.f;
+    for (int e = tid; e < 32 * 32; e += 256) {              // one float4 of one key row per step
+        const int kk = e >> 5, d0 = (e & 31) * 4;
+        const int key = stage * 32 + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * 128 + d0);
+        float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+        n2max = fmaxf(n2max, n2);
+        typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = v[u] * SCALE_X;
+            const h16 h = (h16)sc;
+            hh[u] = h;
+            ll[u] = (h16)(sc - (float)h);
+        }
+        *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
+        *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+    }
+    if (tid < 64) {                                          // the 16 pad bytes of every row (never read as data)
+        const int kk = tid & 31, pl = tid >> 5;
+        *(uint4*)(dst + pl * L::XPLANE + kk * L::XROW + 256) = make_uint4(0, 0, 0, 0);
+    }
+    const float b = bw[cloud];
+    if (!((n2max - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void ms_split_d_kernel(const float* __restrict__ X, const float* __restrict__ bw,
+                                                         uint8_t* __restrict__ blob, int* __restrict__ flags, int N, int nst) {
+    using L = StageLayoutD<NT>;
+    constexpr int D = L::D, Q4 = D / 4;                       // float4s per row
+    const int stage = blockIdx.x, cloud = blockIdx.y, tid = threadIdx.x;
+    const float* Xc = X + (size_t)cloud * N * D;
+    uint8_t* dst = blob + ((size_t)cloud * nst + stage) * L::STAGE;
+    __shared__ float n2row[32];
+    if (tid < 32) n2row[tid] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < 32 * Q4; e += 256) {
+        const int kk = e / Q4, d0 = (e - kk * Q4) * 4;
+        const int key = stage * 32 + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) v = *(const f32x4*)(Xc + (size_t)key * D + d0);
+        atomicAdd(&n2row[kk], v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);   // only compared with a threshold: order-free
+        typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+        h16x4 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sc = v[u] * SCALE_X;
+            const h16 h = (h16)sc;
+            hh[u] = h;
+            ll[u] = (h16)(sc - (float)h);
+        }
+        *(h16x4*)(dst + L::OFF_XH + kk * L::XROW + 2 * d0) = hh;
+        *(h16x4*)(dst + L::OFF_XL + kk * L::XROW + 2 * d0) = ll;
+    }
+    if (tid < 64) {
+        const int kk = tid & 31, pl = tid >> 5;
+        *(uint4*)(dst + pl * L::XPLANE + kk * L::XROW + 2 * D) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float b = bw[cloud];
+        if (!((n2row[tid] - 1.0f) / (b * b) <= 1.0f)) atomicOr(flags + cloud, 1);
+    }
+}
+}  // namespace

@@ -833,12 +833,14 @@ size_t ms_f16_chunked_workspace_bytes(int B, int N, int d);
 int ms_f16_chunked_launch(int B, int N, int d, int S, int iters, const float* bw, const float* X, float* newX, void* workspace,
                           int** flags_out, int (*combine)(const float*, const float*, const float*, float*, size_t, int,
                                                           int, int, int*, hipStream_t),
-                          int digits, int wq, hipStream_t stream);
+                          int digits, hipStream_t stream);
 size_t ms_f16_workspace_bytes(int B, int N, int d);
 int ms_f16_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
-                  int** flags_out, int digits, int wq, hipStream_t stream);
+                  int** flags_out, int digits, hipStream_t stream);
 
-size_t ms_f16_sparse_workspace_bytes(int B, int N);
+size_t ms_f16_sparse_workspace_bytes(int B, int N, int d);
+const char* ms_f16_sparse_kernel_name(int d, int digits);
+const char* ms_f16_kernel_name(int d, bool chunked, int digits);
 int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream);
@@ -851,14 +853,11 @@ static int ms_combine_launch(const float* partO, const float* partS, const float
 }
 
 // Per-call options (include/sednet_hip.h: sed_ms_options_t); NULL = defaults. The library keeps no state between calls.
-struct sed_ms_options { int schedule; int weight_digits; int wave_queries; };
-constexpr int MS_DEFAULT_WAVE_QUERIES = 64;     // same bits as 32; half the LDS reads per MFMA, no scratch (ms_iterate_f16.hip)
+struct sed_ms_options { int schedule; int weight_digits; };
 static int opt_schedule(const sed_ms_options* o) { return o ? o->schedule : 0; }
 static int opt_digits(const sed_ms_options* o) { return (o && o->weight_digits == 1) ? 1 : 2; }     // 0 = default = 2
-static int opt_wq(const sed_ms_options* o) { return (o && o->wave_queries) ? o->wave_queries : MS_DEFAULT_WAVE_QUERIES; }
 static bool opt_valid(const sed_ms_options* o) {
-    return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2 &&
-                  (o->wave_queries == 0 || o->wave_queries == 32 || o->wave_queries == 64));
+    return !o || (o->schedule >= 0 && o->schedule <= 5 && o->weight_digits >= 0 && o->weight_digits <= 2);
 }
 
 // which schedule sed_ms_iterate_ws_f32 runs for this shape when given the workspace it asks for:
@@ -891,7 +890,7 @@ extern "C" int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* b
 extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                      void* workspace, size_t workspace_bytes, const sed_ms_options* opt, hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !opt_valid(opt)) return SED_EINVAL;
-    const int forced = opt_schedule(opt), digits = opt_digits(opt), wq = opt_wq(opt);
+    const int forced = opt_schedule(opt), digits = opt_digits(opt);
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     dim3 grid((N + 127) / 128, B), block(256);
     const int S = ms_chunks(N);
@@ -903,9 +902,9 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     if (plan == MS_F16 || plan == MS_F16_CHUNKED) {
         int* flags = nullptr;
         const int rc = (plan == MS_F16 && d != 160)
-                           ? ms_f16_launch(B, N, d, iters, bw, X, newX, workspace, &flags, digits, wq, stream)
+                           ? ms_f16_launch(B, N, d, iters, bw, X, newX, workspace, &flags, digits, stream)
                            : ms_f16_chunked_launch(B, N, d, plan == MS_F16 ? 1 : ms_f16_chunks(N), iters, bw, X, newX, workspace,
-                                                   &flags, ms_combine_launch, digits, wq, stream);
+                                                   &flags, ms_combine_launch, digits, stream);
         if (rc != SED_OK) return rc;
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud
@@ -999,7 +998,7 @@ extern "C" int sed_ms_iterate_bounds_f16_refs(int N) { return N > 0 ? 2 * ((((N 
 
 extern "C" size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return ms_f16_sparse_workspace_bytes(B, N);
+    return ms_f16_sparse_workspace_bytes(B, N, 160);        // sized for the wider of the two embeddings
 }
 
 extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X,
@@ -1008,10 +1007,10 @@ extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, con
                                              size_t workspace_bytes, void* stats, int weight_digits, int form,
                                              hipStream_t stream) {
     if (B <= 0 || N <= 0 || iters < 0 || !bw || !X || !newX || !(skip_below < 0.f) || !tile_ref || !tile_cosalpha ||
-        margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2 || form < 0 || form > 5)
+        margin < 0.f || !workspace || weight_digits < 0 || weight_digits > 2 || form < 0 || form > 1)
         return SED_EINVAL;
     if (d != 128 && d != 160) return SED_EUNSUPPORTED;
-    if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N)) return SED_EINVAL;
+    if (workspace_bytes < ms_f16_sparse_workspace_bytes(B, N, d)) return SED_EINVAL;
     if (iters == 0) {                                       // zero iterations: the rows themselves
         const hipError_t e = hipMemcpyAsync(newX, X, (size_t)B * N * d * sizeof(float), hipMemcpyDeviceToDevice, stream);
         return e == hipSuccess ? SED_OK : (int)e;

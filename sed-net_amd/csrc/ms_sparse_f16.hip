@@ -1,0 +1,753 @@
+// Mean-shift iterations, BLOCK-SPARSE schedule on the fp16 matrix pipe (split-fp16 arithmetic: ms_f16_common.h; mathematics:
+// /root/reference/src/mean_shift.py:56-77, guard.py:7-9). d = 128, or 160 (the HPNet-widened embedding).
+//
+// Rows arrive sorted so that 32-row tiles -- here: stage images -- are cluster-pure (ms_sparse_prep.hip), together with two unit
+// reference vectors per tile (normalised means of two groups of its rows) and cos(alpha) of each, alpha = the widest angle between
+// the reference and a row of its group. One work item = 128 query rows (4 waves x 32) of one cloud for ALL iterations. Every
+// iteration
+//   (1) when a query of the workgroup has turned by more than DELTA since the masks were made (25 of 50 iterations on a trained
+//       network's embedding), every wave measures its 32 current queries against ALL tile references: S = M Q^T on the matrix
+//       pipe (fp16 head parts only: |error| <= 5e-4 in the dot product, covered by the threshold's slack), 8 MFMAs per 32
+//       references, and marks the stages it needs: by the triangle inequality on the unit sphere angle(q, x) >= angle(q, m) - alpha
+//       for every key x within alpha of a reference m, so a tile all of whose rows lie in caps with
+//       q . m <= cos(theta + alpha + margin + DELTA) - slack for all 32 queries carries only weights <= e^skip for them (theta =
+//       the angle at which the kernel weight drops to e^skip). A tile has TWO references, each covering a part of its rows: the
+//       tile at the border between two clusters of the sorted order would otherwise be wide open and needed by everybody;
+//   (2) the workgroup compacts the union of its waves' marks into a stage list (thread s owns stage s, s + 256: nst <= 512);
+//   (3) the list is walked through 4 (d = 160: 3) LDS stage buffers filled by LDS-DMA, one barrier per listed stage. A wave that
+//       does not need a listed stage only takes part in its barrier. A wave that needs it runs the first product (24 MFMAs at
+//       d = 128), the exponentials and the (h, l) split of the weights, and -- unless all its weights rounded to (0, 0) -- the second
+//       product (24 MFMAs). Between mask rebuilds the masks are REFINED exactly: a wave that finds all weights of a block below
+//       2^-25 e^(-4 DELTA / b^2) (scaled units) clears the stage in its own mask -- every query is within 2 DELTA of where it is
+//       now until the next rebuild, a chord <= 2 changes by <= 2 DELTA and the exponent by <= 4 DELTA / b^2, so the weights stay
+//       below the fp16 flush point: exactly the blocks whose second product would be skipped anyway. The list is remade every
+//       sweep, so a stage nobody needs any more costs no copy and no barrier. Lists are walked in alternating direction (an
+//       iteration starts on the stages the previous one left in L2).
+// What is dropped relative to the dense kernel: weights <= e^skip in whole blocks, <= N e^skip of a row sum (>= 1). The Python
+// mirror passes skip = ln 2^-39, the weight below which fp16(2^14 p) rounds to zero in the dense split-fp16 kernel as well.
+//
+// Scheduling: PERSISTENT workgroups (two per CU: 256 registers per wave) on per-XCD work queues. A counting launch of the same
+// kernel builds every item's first stage list and stores its length; ms_sparse_item_order_kernel (one workgroup) ranks the
+// clouds by total length, deals them to the 8 XCDs in snake order and writes each XCD's queue -- its clouds heaviest first, a
+// cloud's items longest first; the iteration launch has exactly as many workgroups as fit and a workgroup pops its XCD's queue
+// (s_getreg XCC_ID, one atomic per item), then the following XCDs' queues. A work item is independent of every other item:
+// a cloud's result does not depend on what else is in the launch.
+//
+// Round 4 (this file; the round-3 kernel with its 8-wave / four-plane / list-driven forms is archived in
+// tools/experiments/ms_iterate_f16_round3.hip): the weight phase issues ~85 instead of ~130 vector instructions per block (packed
+// fp32 fma for the exponent, no clamp -- a weight below e^-75 changes neither the fp32 row sum, which holds the self weight 2^14,
+// nor the (h, l) digits, which are 0 below 2^-39 --, liveness from the packed fp16 heads, the dead-stage test only on blocks that
+// are not live), the late / early wave staggering is gone (it measured +-0), and with F16S_ASM_RING the operand ring is read by
+// inline ds_read instructions with hand-counted lgkmcnt waits and the per-stage barrier waits only for the stage copy it needs
+// (vmcnt(one entry) instead of vmcnt(0): the compiler puts s_waitcnt vmcnt(0) in front of every transpose read while LDS-DMA
+// copies are in flight, which ties the prefetch distance to one stage whatever the number of buffers).
+#include "ms_f16_common.h"
+#include <type_traits>
+
+#ifndef F16S_ASM_RING
+#define F16S_ASM_RING 1
+#endif
+#ifndef F16S_DELTA_V
+#define F16S_DELTA_V 0.005f
+#endif
+
+namespace {
+
+constexpr int F16S_NW = 4;                        // waves per workgroup: 128 query rows, two workgroups per CU
+constexpr int F16S_MAXW = 8;                      // 64-bit words of a stage mask: 512 stages = 16 384 points
+constexpr int F16S_REFGROUP = 12;                 // reference images per LDS load
+constexpr float F16S_DELTA = F16S_DELTA_V;        // masks stay valid while no query has turned by more than this (rad)
+
+// Work queue of the persistent kernel. sched (ints): [0 .. 2] heads of natural-order queues (counting launch; item_list == NULL),
+// [8 .. 15] / [16 .. 23] heads of the per-XCD queues (iteration launch / its (h, l) redo), [24 .. 31] start and [32 .. 39] length of
+// XCD x's queue inside item_list. An item = (cloud << 8) | block of query rows.
+constexpr int MS_SCHED_INTS = 64;
+__device__ __forceinline__ int ms_next_item(int* __restrict__ sched, const int* __restrict__ item_list, int head0, int nitems, int nbx) {
+    if (item_list == nullptr) {
+        const int j = atomicAdd(sched + head0, 1);          // natural order: head0 = the launch's own counter (0, 1, 2)
+        return j >= nitems ? -1 : ((j / nbx) << 8) | (j % nbx);
+    }
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;          // HW_REG_XCC_ID[3:0]
+    for (int s = 0; s < 8; ++s) {
+        const int x = (xcc + s) & 7;
+        const int len = sched[32 + x];
+        if (len > 0 && __hip_atomic_load(sched + head0 + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len) {
+            const int j = atomicAdd(sched + head0 + x, 1);
+            if (j < len) return item_list[sched[24 + x] + j];
+        }
+    }
+    return -1;
+}
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (A < B) {
+        f(ic<A>{});
+        static_for<A + 1, B>(f);
+    }
+}
+
+// LDS instructions of operand-ring step u (mod 4 NT): 2 (first-product operands: one ds_read_b128 per plane) or 4 (transpose reads)
+template <int NT>
+__host__ __device__ constexpr int f16s_ring_ops(int u) { return (u % (4 * NT)) < 2 * NT ? 2 : 4; }
+
+typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+
+#if F16S_ASM_RING
+// LDS reads the compiler's waitcnt pass does not see (it would wait for every LDS-DMA copy in flight before them); the consumer
+// waits through ring_wait<N>: N = LDS instructions issued after the ones whose result is wanted (LDS returns in order).
+template <int OFF>
+__device__ __forceinline__ h16x8 lds_read_b128(unsigned addr) {
+    h16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ v4s lds_read_tr16_b64(unsigned addr) {
+    v4s v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void ring_wait(h16x8& a, h16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+#endif
+
+template <bool PL, int NT>     // PL = false: fp16 heads of the weights only (weight_digits = 1, see ms_iterate_f16.hip)
+__global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
+    const float* __restrict__ X, const uint8_t* __restrict__ blob, float* __restrict__ newX,
+    const float* __restrict__ bw, const int* __restrict__ flags, int N, int iters, float skip_below,
+    const uint8_t* __restrict__ refblob, const float* __restrict__ tile_cosalpha, float margin,
+    unsigned long long* __restrict__ stats, int* __restrict__ lowq, int nitems, const int* __restrict__ item_list,
+    int* __restrict__ sched, int head0, int* __restrict__ item_stages) {
+    using LR = StageLayoutD<NT>;
+    constexpr int NW = F16S_NW;
+    constexpr int D = 32 * NT, KS = 2 * NT, NSTEP = 4 * NT;      // feature width, k-steps of the first product, operand steps of a block
+    constexpr int XROW = LR::XROW, STAGE = LR::STAGE, NPIECE = STAGE / 1024;
+    constexpr int OFF_XL = LR::OFF_XL;
+    constexpr int MAXW = F16S_MAXW;
+    constexpr int NBUF = NT == 4 ? 4 : 3;                         // 2 workgroups x NBUF x 17 / 21 KiB + tables <= 160 KiB
+    constexpr int PW = NPIECE / NW;                               // DMA instructions EVERY wave issues per stage (wave 0: one more)
+    constexpr int REFP = (32 * XROW + 1023) / 1024, REFB = REFP * 1024;       // DMA pieces / bytes that cover an image's head plane
+    constexpr int REFG = NBUF * STAGE / REFB < F16S_REFGROUP ? NBUF * STAGE / REFB : F16S_REFGROUP;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];    // [NBUF][STAGE]
+    __shared__ unsigned long long wmask[NW][MAXW];
+    __shared__ int slist[512];
+    __shared__ int wcount[NW];
+    __shared__ int item_sh;
+    __shared__ float wmoved[NW];
+    __shared__ __attribute__((aligned(16))) float thr[2 * 64 * MAXW]; // per reference: q . m (scaled 2^22) above which it is near
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    constexpr int QB = 32 * NW;                           // query rows per workgroup
+    const int nbx = (N + QB - 1) / QB;
+    const int nst = (N + 31) >> 5;
+    const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
+    unsigned n_listed = 0, n_first = 0, n_second = 0, n_remake = 0, n_dense = 0;      // wave-uniform counts (statistics only)
+    for (;;) {
+    __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
+    if (tid == 0) item_sh = ms_next_item(sched, item_list, head0, nitems, nbx);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(item_sh);
+    if (item < 0) break;
+    const int bx = item & 0xff;
+    const int cloud = item >> 8;
+    [&]() __attribute__((always_inline)) {
+    if (flags[cloud]) return;
+    if (PL && lowq != nullptr && !lowq[cloud]) return;     // second pass: only the clouds the heads-only pass has flagged
+    const float* Xc = X + (size_t)cloud * N * D;
+    const uint8_t* ref_c = refblob + (size_t)cloud * nrs * STAGE;
+    const uint8_t* blob_c = blob + (size_t)cloud * nst * STAGE;
+    const int qrow = bx * QB + wave * 32 + li;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    float* const myrow = newX + ((size_t)cloud * N + qrow_c) * D;      // the row's slot of the output: parks the row at mask time
+
+    const float b = bw[cloud];
+    const float inv_b2_l2e = 1.44269504088896340736f / (b * b);
+    const float K1 = inv_b2_l2e * (1.0f / 4194304.0f);
+    const float K0 = LOG2_SCALE_P - inv_b2_l2e;
+    {   // thresholds: reference rho is "near" a query with  q . m_rho > cos(theta + alpha_rho + margin) - slack
+        const float Dthr = -2.0f * skip_below * b * b;   // dist >= Dthr  <=>  weight <= e^skip
+        const float theta = Dthr < 3.99f ? acosf(1.0f - 0.5f * Dthr) + margin + F16S_DELTA : 1.0e9f;
+        for (int rho = tid; rho < 2 * 64 * MAXW; rho += 64 * NW) {
+            float v = 3.0e38f;                           // references of tiles past the end: never near
+            const int t = (rho >> 6) * 32 + (rho & 31);  // image rho / 32 = 2 (t / 32) + which reference
+            if (t < nst) {
+                const float ca = fminf(fmaxf(tile_cosalpha[(size_t)cloud * nrs * 32 + rho], -1.0f), 1.0f);
+                const float ang = theta + acosf(ca);
+                v = ang < 3.14f ? (cosf(ang) - 1.0e-3f) * (SCALE_X * SCALE_X) : -3.0e38f;        // -3e38: always near
+            }
+            thr[rho] = v;
+        }
+    }
+    const float dead_below = 2.98023223876953125e-8f * 0.5f * __expf(-4.0f * F16S_DELTA / (b * b));
+    h16x8 qh[KS], ql[KS];
+    auto split_q = [&](int ks, const float* v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const h16 h = (h16)v[i];
+            qh[ks][i] = h;
+            ql[ks][i] = (h16)(v[i] - (float)h);
+        }
+    };
+    // Q operand of k-step ks on lane half hi: features 16 ks + 8 hi + 0..7 (the image's own order; the row update exchanges four
+    // values per k-step with the other lane half)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 t = *(const f32x4*)(Xc + (size_t)qrow_c * D + 16 * ks + 8 * hi + 4 * g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * g + u] = t[u] * SCALE_X;
+        }
+        split_q(ks, v);
+    }
+
+    const unsigned lane16 = lane * 16;
+    auto stage_dma = [&](int st, int buf) {              // 17 / 21 pieces of 1 KiB dealt round-robin to the waves
+        const uint8_t* src = blob_c + (size_t)st * STAGE;
+        uint8_t* dst = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
+            const int pc = wave + NW * i;
+            if (pc < NPIECE)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024 + lane16),
+                                                 (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    // The A operands of both products travel through a 4-slot register ring loaded three MFMA steps ahead of their use, across the
+    // phase boundary and across blocks. Step t < KS: 8 features of key sigma(li) (first product: key rows in sigma order so that its
+    // accumulator rows are in the transpose read's key order); step t >= KS: 8 keys of feature tile (t - KS) / 2, half (t - KS) % 2
+    // through the transpose read (second product).
+    h16x8 fa[4], fb[4];
+    const int xoff_nat = li * XROW + hi * 16;             // natural row order (reference planes)
+    const int xoff = (16 * (li >> 4) + 4 * (li & 3) + ((li >> 2) & 3)) * XROW + hi * 16;
+    const int toff = (4 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+#if F16S_ASM_RING
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    auto ring_load = [&](auto tc, int buf) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t < KS) {
+            const unsigned a = lds0 + (unsigned)(buf * STAGE + xoff);
+            fa[t & 3] = lds_read_b128<t * 32>(a);
+            fb[t & 3] = lds_read_b128<OFF_XL + t * 32>(a);
+        } else {
+            constexpr int c = (t - KS) >> 1, j = (t - KS) & 1;
+            const unsigned a = lds0 + (unsigned)(buf * STAGE + toff);
+            const v4s h0 = lds_read_tr16_b64<(16 * j) * XROW + 64 * c>(a);
+            const v4s h1 = lds_read_tr16_b64<(16 * j + 2) * XROW + 64 * c>(a);
+            const v4s l0 = lds_read_tr16_b64<OFF_XL + (16 * j) * XROW + 64 * c>(a);
+            const v4s l1 = lds_read_tr16_b64<OFF_XL + (16 * j + 2) * XROW + 64 * c>(a);
+            fa[t & 3] = __builtin_bit_cast(h16x8, (v8s)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            fb[t & 3] = __builtin_bit_cast(h16x8, (v8s)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+#else
+    auto tr8 = [&](const uint8_t* plane, int c, int j) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
+        const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j + 2) * XROW + 64 * c));
+        return __builtin_bit_cast(h16x8, (v8s)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto ring_load = [&](auto tc, int buf) {
+        constexpr int t = decltype(tc)::value;
+        const uint8_t* base = lds + buf * STAGE;
+        if constexpr (t < KS) {
+            fa[t & 3] = *(const h16x8*)(base + xoff + t * 32);
+            fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+        } else {
+            constexpr int c = (t - KS) >> 1, j = (t - KS) & 1;
+            fa[t & 3] = tr8(base, c, j);
+            fb[t & 3] = tr8(base + OFF_XL, c, j);
+        }
+    };
+#endif
+    // the stage barrier: every wave's share of the NEXT entry's copy has landed (the newest entry -- issued NBUF - 1 entries ahead
+    // -- may still be in flight where a newer one exists), LDS writes are visible
+    auto stage_barrier = [&](bool newest_is_needed) {
+#if F16S_ASM_RING
+        if (NBUF < 4 || newest_is_needed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#endif
+    };
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float rsum = 0.f;
+    h16x8 ph[2], pl[2];
+
+    // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
+    // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
+    // The rows at mask time are parked in the output rows (row-private; overwritten by the result at the end).
+    int ns = 0;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();                                 // every wave is out of the previous iteration's stage buffers
+        bool remake = it == 0;
+        if (it > 0) {
+            float mx = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mx = fmaxf(mx, wmoved[w]);
+            remake = !(mx <= F16S_DELTA);
+        }
+        if (remake) {
+        if (qrow < N) {                                  // remember where the masks were made (Q-operand order, read back by the same lane)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = ((float)qh[ks][4 * g + u] + (float)ql[ks][4 * g + u]) * UNSCALE_Q;
+                    *(f32x4*)(myrow + 16 * ks + 8 * hi + 4 * g) = v;
+                }
+        }
+        // ---- (1): this wave's queries against all tile references -> its stage mask
+        for (int g0 = 0; g0 < nrs; g0 += REFG) {
+            const int ng = min(REFG, nrs - g0);
+            if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
+            for (int pc = wave; pc < ng * REFP; pc += NW) {   // 1 KiB pieces: image pc / REFP, piece pc % REFP
+                const int im = pc / REFP, piece = pc - REFP * im;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
+                    (__attribute__((address_space(3))) void*)(lds + im * REFB + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int im = 0; im < ng; ++im) {
+                const uint8_t* rbase = lds + im * REFB + xoff_nat;
+                f32x16 sr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < KS; ++t) sr = mfma16(*(const h16x8*)(rbase + t * 32), qh[t], sr);
+                unsigned word = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 th = *(const f32x4*)(thr + (g0 + im) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(sr[4 * g + u] > th[u]);
+                        word |= ((unsigned)bal != 0u ? 1u : 0u) << (8 * g + u);              // tile row of lane half 0
+                        word |= ((unsigned)(bal >> 32) != 0u ? 1u : 0u) << (8 * g + u + 4);  // ... of lane half 1
+                    }
+                }
+                if (lane == 0) {                                  // a tile is needed if either of its references is near
+                    unsigned* wm = (unsigned*)wmask[wave] + ((g0 + im) >> 1);
+                    *wm = ((g0 + im) & 1) ? (*wm | word) : word;
+                }
+            }
+        }
+        if (lane == 0 && ((nrs >> 1) & 1)) ((unsigned*)wmask[wave])[nrs >> 1] = 0u;      // upper half of the last 64-bit word
+        __syncthreads();
+        ++n_remake;
+        }   // remake
+        // ---- (2) the workgroup's stage list, ascending: thread s owns stage s (s + 256 in a second pass). Made in EVERY sweep:
+        // between mask rebuilds the waves take dead stages out of their masks (below), and a stage no wave needs any more leaves
+        // the list -- no copy, no barrier for it.
+        ns = 0;
+        for (int s0 = 0; s0 < nst; s0 += 64 * NW) {
+            const int st = s0 + tid;
+            bool need = false;
+            if (st < nst) {
+                const int w = st >> 6, sh = st & 63;
+                unsigned long long any = 0ull;
+#pragma unroll
+                for (int v = 0; v < NW; ++v) any |= wmask[v][w];
+                need = (any >> sh) & 1ull;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (s0 > 0) __syncthreads();                  // wcount of the previous pass has been read
+            if (lane == 0) wcount[wave] = __builtin_popcountll(bal);
+            __syncthreads();
+            int base = ns;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int cnt = wcount[w];
+                if (w < wave) base += cnt;
+                ns += cnt;
+            }
+            if (need) slist[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = st;
+        }
+        __syncthreads();
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        if (item_stages != nullptr) {                     // counting launch: the length of the first list is all that is wanted
+            if (tid == 0) item_stages[cloud * nbx + bx] = ns;
+            return;
+        }
+        n_listed += ns;
+        n_dense += nst;
+
+        // ---- (3) the pipeline over the list
+        const bool fwd = (it & 1) == 0;
+        auto entry = [&](int j) { return __builtin_amdgcn_readfirstlane(slist[fwd ? j : ns - 1 - j]); };
+#pragma unroll
+        for (int j0 = 0; j0 < NBUF - 1; ++j0)
+            if (j0 < ns) stage_dma(entry(j0), j0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ns > 0) static_for<0, 3>([&](auto tc) { ring_load(tc, 0); });
+        int buf = 0;
+        for (int j = 0; j < ns; ++j) {
+            const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+            const int st = entry(j);
+            const int key0 = st * 32;
+            const bool more = j + 1 < ns;                 // the ring goes on into the next listed stage
+            const bool need =
+                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            bool live = false;
+            if (need) {
+                // ---- first product S^T = X_tile Q^T (keys on accumulator rows) ...
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                static_for<0, KS>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+#if F16S_ASM_RING
+                    ring_wait<f16s_ring_ops<NT>(t + 1) + f16s_ring_ops<NT>(t + 2)>(fa[t & 3], fb[t & 3]);
+#endif
+                    s = mfma16(fb[t & 3], qh[t], s);
+                    s = mfma16(fa[t & 3], ql[t], s);
+                    s = mfma16(fa[t & 3], qh[t], s);
+                    ring_load(ic<t + 3>{}, buf);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // ---- ... the kernel weights 2^14 p = exp2(K1 S + K0) (guard.py's clamp at -75 drops out: see the file header) ...
+                const f32x2 k1 = {K1, K1}, k0 = {K0, K0};
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 sv = {s[r], s[r + 1]};
+                    const f32x2 t2 = __builtin_elementwise_fma(sv, k1, k0);
+                    p[r] = __builtin_amdgcn_exp2f(t2[0]);
+                    p[r + 1] = __builtin_amdgcn_exp2f(t2[1]);
+                }
+                if (key0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + sigma_row(mfma_row(r, hi)) >= N) p[r] = 0.f;
+                }
+                // ... and their (h, l) digits
+                unsigned anyh = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 pv = {p[r], p[r + 1]};
+                    const h16x2 h = __builtin_convertvector(pv, h16x2);
+                    ph[r >> 3][r & 7] = h[0];
+                    ph[r >> 3][(r & 7) + 1] = h[1];
+                    anyh |= __builtin_bit_cast(unsigned, h);
+                    if (PL) {
+                        rsum += p[r];
+                        rsum += p[r + 1];
+                        const f32x2 hf = {(float)h[0], (float)h[1]};
+                        const h16x2 l = __builtin_convertvector(pv - hf, h16x2);
+                        pl[r >> 3][r & 7] = l[0];
+                        pl[r >> 3][(r & 7) + 1] = l[1];
+                    } else {
+                        rsum += (float)h[0];
+                        rsum += (float)h[1];
+                    }
+                }
+                // p 2^14 <= 2^-25 rounds to (h, l) = (0, 0) (l is the rounding of p - h = p < 2^-25 as well): the second product of a
+                // block without a nonzero head adds exactly nothing
+                live = __builtin_amdgcn_ballot_w64(anyh != 0u) != 0ull;
+                if (!live) {
+                    // ... and a block whose largest weight is below 2^-25 e^(-4 delta / b^2) stays that way until the masks are remade
+                    // (file header): the wave drops the stage from its OWN mask
+                    float pmax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, p[r]);
+                    if (__builtin_amdgcn_ballot_w64(pmax > dead_below) == 0ull && lane == 0)
+                        wmask[wave][st >> 6] &= ~(1ull << (st & 63));
+                }
+                ++n_first;
+            }
+            // B_j: every wave is past entry j - 1 (its buffer is free) and has entry j + 1's copy in LDS
+            stage_barrier(j + NBUF - 1 > ns);
+            // entry j + NBUF - 1 goes into the buffer entry j - 1 has left
+            if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
+
+            if (live) {
+                ++n_second;
+                static_for<KS, NSTEP>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int c = (t - KS) >> 1, jj = (t - KS) & 1;
+#if F16S_ASM_RING
+                    // steps t + 1, t + 2 past the end of the block load the next stage's first operands only when there is one
+                    constexpr int in_block = (t + 1 < NSTEP ? f16s_ring_ops<NT>(t + 1) : 0) + (t + 2 < NSTEP ? f16s_ring_ops<NT>(t + 2) : 0);
+                    constexpr int beyond = (t + 1 >= NSTEP ? 2 : 0) + (t + 2 >= NSTEP ? 2 : 0);
+                    if (beyond == 0 || !more) ring_wait<in_block>(fa[t & 3], fb[t & 3]);
+                    else ring_wait<in_block + beyond>(fa[t & 3], fb[t & 3]);
+#endif
+                    o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
+                    if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
+                    o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if constexpr (t + 3 < NSTEP) ring_load(ic<t + 3>{}, buf);
+                    else if (more) ring_load(ic<t + 3 - NSTEP>{}, nbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else if (more) {
+#if F16S_ASM_RING
+                // (the ring may hold transpose reads in flight whose slots the loads below reuse: drain first)
+                if (need) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                static_for<0, 3>([&](auto tc) { ring_load(tc, nbuf); });
+            }
+            buf = nbuf;
+        }
+#if F16S_ASM_RING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of the ring is in flight past the sweep
+#endif
+
+        // ---- row update (mean_shift.py:70-77)
+        const float rs = rsum + xor32(rsum);
+        const float Dinv = UNSCALE_O / rs;
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float qacc[16];                               // the current row in accumulator order
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float e0 = ((float)qh[2 * c + j][u] + (float)ql[2 * c + j][u]) * UNSCALE_Q;
+                    const float e1 = ((float)qh[2 * c + j][4 + u] + (float)ql[2 * c + j][4 + u]) * UNSCALE_Q;
+                    const float keep_ = hi ? e1 : e0, send = hi ? e0 : e1;
+                    const float recv = __shfl_xor(send, 32, 64);
+                    qacc[8 * j + u] = hi ? recv : keep_;
+                    qacc[8 * j + 4 + u] = hi ? keep_ : recv;
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = qacc[r];
+                const float m = o[c][r] * Dinv - q;
+                const float nq = q + m;
+                o[c][r] = nq;
+                n2 += nq * nq;
+            }
+        }
+        n2 += xor32(n2);
+        const float nrm = sqrtf(n2);
+        if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;       // weighted mean cancels: see ms_iterate_f16.hip
+        if (it + 1 < iters) {   // new Q operand (exchange with the other lane half) and how far it is from where the masks were
+            float ch2 = 0.f;    // made (angle <= 1.06 chord for chords <= 0.6)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a_ = (o[c][8 * j + u] / nrm) * SCALE_X, b_ = (o[c][8 * j + 4 + u] / nrm) * SCALE_X;
+                        const float keep_ = hi ? b_ : a_, send = hi ? a_ : b_;
+                        const float recv = __shfl_xor(send, 32, 64);
+                        v[u] = hi ? recv : keep_;
+                        v[4 + u] = hi ? keep_ : recv;
+                    }
+                    const f32x4 k0_ = *(const f32x4*)(myrow + 8 * hi + 16 * (2 * c + j));
+                    const f32x4 k1_ = *(const f32x4*)(myrow + 8 * hi + 16 * (2 * c + j) + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d0 = v[u] * UNSCALE_Q - k0_[u], d1 = v[4 + u] * UNSCALE_Q - k1_[u];
+                        ch2 = fmaf(d0, d0, fmaf(d1, d1, ch2));
+                    }
+                    split_q(2 * c + j, v);
+                }
+            if (qrow >= N) ch2 = 0.f;
+            ch2 += xor32(ch2);
+            float wm = ch2 <= 0.36f ? 1.06f * sqrtf(ch2) : 1.0e9f;          // NaN -> 1e9
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+            if (lane == 0) wmoved[wave] = wm;            // read after the barrier that opens the next iteration
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+            rsum = 0.f;
+        } else if (qrow < N) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {o[c][4 * g] / nrm, o[c][4 * g + 1] / nrm, o[c][4 * g + 2] / nrm, o[c][4 * g + 3] / nrm};
+                    *(f32x4*)(myrow + 32 * c + 8 * g + 4 * hi) = v;
+                }
+        }
+    }
+    }();
+    }   // work items
+    if (stats && lane == 0 && item_stages == nullptr) {
+        // [0] stage visits of workgroups (listed), [1] first products of waves, [2] second products of waves,
+        // [3] dense count: waves x stages x iterations, [4] mask / list constructions of workgroups
+        if (wave == 0) atomicAdd(stats + 0, (unsigned long long)n_listed);
+        atomicAdd(stats + 1, (unsigned long long)n_first);
+        atomicAdd(stats + 2, (unsigned long long)n_second);
+        atomicAdd(stats + 3, (unsigned long long)n_dense);
+        if (wave == 0) atomicAdd(stats + 4, (unsigned long long)n_remake);
+    }
+}
+
+// The per-XCD item queues of the persistent kernel (layout: ms_next_item) from the first stage-list length of every item: clouds
+// ranked by their total length and dealt to the 8 XCDs in snake order (equal shares of the work), every XCD's queue = its clouds
+// one after the other, heaviest first. A cloud's items: longest first (row_order = 0: the launch ends on short items) or in row
+// order (row_order = 1: the items resident on an XCD at one time are neighbours in the sorted order, i.e. queries of the same
+// clusters that need the same stages -- a smaller working set in the XCD's L2). What is left over at the end is taken by the
+// XCDs that finish early. One workgroup; B <= MS_ORDER_MAX_CLOUDS.
+constexpr int MS_ORDER_MAX_CLOUDS = 4096;
+__global__ __launch_bounds__(1024) void ms_sparse_item_order_kernel(const int* __restrict__ item_stages, int B, int nbx,
+                                                                    int* __restrict__ item_list, int* __restrict__ sched, int row_order) {
+    __shared__ int total[MS_ORDER_MAX_CLOUDS];
+    __shared__ unsigned short rank_of[MS_ORDER_MAX_CLOUDS];
+    __shared__ int nclouds[8], qstart[8];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < B; c += 1024) {
+        int t = 0;
+        for (int b = 0; b < nbx; ++b) t += item_stages[c * nbx + b];
+        total[c] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < B; c += 1024) {                  // rank by (total descending, cloud ascending)
+        const int t = total[c];
+        int r = 0;
+        for (int o = 0; o < B; ++o) r += (total[o] > t || (total[o] == t && o < c)) ? 1 : 0;
+        rank_of[c] = (unsigned short)r;
+    }
+    if (tid < 8) {                                         // ranks 8 m + j go to XCD j (m even) or 7 - j (m odd)
+        int n = 0;
+        for (int r = 0; r < B; ++r) n += (((r >> 3) & 1) ? 7 - (r & 7) : (r & 7)) == tid ? 1 : 0;
+        nclouds[tid] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int x = 0; x < 8; ++x) { qstart[x] = acc; acc += nclouds[x] * nbx; }
+    }
+    __syncthreads();
+    if (tid < 8) { sched[24 + tid] = qstart[tid]; sched[32 + tid] = nclouds[tid] * nbx; }
+    for (int i = tid; i < B * nbx; i += 1024) {
+        const int c = i / nbx, b = i - c * nbx;
+        const int r = rank_of[c], x = ((r >> 3) & 1) ? 7 - (r & 7) : (r & 7);
+        int pos = b;
+        if (!row_order) {                                  // position among the cloud's items: (length descending, block ascending)
+            const int ns = item_stages[i];
+            pos = 0;
+            for (int o = 0; o < nbx; ++o) {
+                const int os = item_stages[c * nbx + o];
+                pos += (os > ns || (os == ns && o < b)) ? 1 : 0;
+            }
+        }
+        item_list[qstart[x] + (r >> 3) * nbx + pos] = (c << 8) | b;
+    }
+}
+
+}  // namespace
+
+static size_t f16s_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
+static size_t f16s_blob_bytes(int B, int N, int d) {
+    return (size_t)B * ((N + 31) / 32) * (d == 160 ? StageLayoutD<5>::STAGE : StageLayoutD<4>::STAGE);
+}
+
+// stage images of the sorted rows | flags | stage images of the tile references | scratch flags | cancel flags | work queues
+size_t ms_f16_sparse_workspace_bytes(int B, int N, int d) {
+    const int nref = 2 * ((((N + 31) / 32) + 31) / 32) * 32;            // reference rows
+    return f16s_blob_bytes(B, N, d) + f16s_blob_bytes(B, nref, d) + 3 * f16s_flag_bytes(B) +
+           (size_t)(MS_SCHED_INTS + 2 * (size_t)B * ((N + 127) / 128)) * sizeof(int);      // + queues, first list lengths, item list
+}
+
+// the template instantiation that runs (as rocprofv3 prints it): bench.py's roofline.kernel
+const char* ms_f16_sparse_kernel_name(int d, int digits) {
+    if (d == 160) return digits == 2 ? "ms_sparse_f16_kernel<true, 5>" : "ms_sparse_f16_kernel<false, 5>";
+    return digits == 2 ? "ms_sparse_f16_kernel<true, 4>" : "ms_sparse_f16_kernel<false, 4>";
+}
+
+template <int NT>
+static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
+                       uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                       float margin, unsigned long long* stats, int digits, int row_order, int* sched, hipStream_t stream) {
+    constexpr int NW = F16S_NW;
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
+    constexpr int sm = (NT == 4 ? 4 : 3) * StageLayoutD<NT>::STAGE;
+    hipError_t e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    if (e != hipSuccess) return (int)e;
+    const int nbx = (N + 32 * NW - 1) / (32 * NW), nitems = nbx * B;
+    if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
+    int dev = 0, slots = 0;                                // resident workgroups: 8 waves of 256 registers per CU
+    e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    slots *= 8 / NW;
+    const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
+    int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
+    int* item_list = item_stages + nitems;
+    const int* listed = B <= MS_ORDER_MAX_CLOUDS ? item_list : nullptr;      // (beyond: items in natural order)
+    e = hipMemsetAsync(sched, 0, (size_t)(MS_SCHED_INTS + nitems) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    if (NT != 4) {
+        ms_split_d_kernel<NT><<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_d_kernel<NT><<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    } else {
+        ms_split_n_kernel<<<dim3(nst, B), 256, 0, stream>>>(X, bw, blob, flags, N, nst);
+        ms_split_n_kernel<<<dim3(nrs, B), 256, 0, stream>>>(tile_ref, bw, refblob, flags2, nrs * 32, nrs);
+    }
+    // first launch: every item builds its first stage list and reports its length; then the items are queued by it
+    ms_sparse_f16_kernel<true, NT><<<grid, 64 * NW, sm, stream>>>(
+        X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, nullptr, nitems, nullptr, sched, 0,
+        item_stages);
+    if (listed) ms_sparse_item_order_kernel<<<1, 1024, 0, stream>>>(item_stages, B, nbx, item_list, sched, row_order);
+    if (digits != 2) {        // heads-only weights; flagged clouds again with (h, l) weights
+        ms_sparse_f16_kernel<false, NT><<<grid, 64 * NW, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, lowq, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
+        ms_sparse_f16_kernel<true, NT><<<grid, 64 * NW, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, nullptr, lowq, nitems, listed, sched,
+            listed ? 16 : 2, nullptr);
+    } else
+        ms_sparse_f16_kernel<true, NT><<<grid, 64 * NW, sm, stream>>>(
+            X, blob, newX, bw, flags, N, iters, skip_below, refblob, tile_cosalpha, margin, stats, nullptr, nitems, listed, sched,
+            listed ? 8 : 1, nullptr);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// Block-sparse split-fp16 schedule on rows sorted into cluster-pure tiles. nref = 64 ceil(ceil(N / 32) / 32) reference rows:
+// row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, d] unit vectors (unused rows zero),
+// tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
+// workspace = ms_f16_sparse_workspace_bytes(B, N, d); stats (optional, device, 5 x u64, accumulated; the redo pass is not counted).
+// form: 0 = default; bit 0 set = a cloud's items are queued in row order instead of longest first.
+int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
+                         int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
+                         float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
+    const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
+    if (nst > 64 * F16S_MAXW) return SED_EUNSUPPORTED;
+    if (d != 128 && d != 160) return SED_EUNSUPPORTED;
+    uint8_t* blob = (uint8_t*)workspace;
+    int* flags = (int*)(blob + f16s_blob_bytes(B, N, d));
+    uint8_t* refblob = (uint8_t*)flags + f16s_flag_bytes(B);
+    int* flags2 = (int*)(refblob + f16s_blob_bytes(B, nrs * 32, d));
+    int* lowq = (int*)((uint8_t*)flags2 + f16s_flag_bytes(B));           // clouds whose weighted means cancel (heads-only pass)
+    int* sched = (int*)((uint8_t*)lowq + f16s_flag_bytes(B));
+    *flags_out = flags;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    const int row_order = form & 1;
+    if (d == 160)
+        return f16s_launch<5>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                              stats, digits, row_order, sched, stream);
+    return f16s_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
+                          stats, digits, row_order, sched, stream);
+}

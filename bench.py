@@ -23,12 +23,12 @@ fp32-equivalent forms everywhere (mean-shift second product with two weight digi
 
 The JSON line also carries
   roofline     : the dominant kernel of the headline step (the mean-shift iteration kernel that took most of it: block-sparse
-                 ms_iterate_d128_f16s_kernel on clustered embeddings, dense ms_iterate_d128_f16w_kernel otherwise), timed live
-                 with events on the launch stream inside the timed region. `achieved` = ALGORITHMIC flops (4 N^2 D iters per
-                 cloud, SURVEY.md section 8(d): what the reference's dense algorithm does) / launch time; `peak` = dense fp16
-                 MFMA peak / fp16 MFMAs per algorithmic product (3: both products on exact (h, l) splits). For the block-sparse
-                 kernel the fraction of the dense work it actually executes is reported too (device counters), and
-                 `executed_frac_of_f16_peak` = executed fp16-MFMA flops / time / 2500 TFLOP/s.
+                 ms_sparse_f16_kernel on clustered embeddings, dense ms_iterate_f16w_kernel otherwise; the name comes from the
+                 library: sed_ms_iterate_*_kernel_name), timed live with events on the launch stream inside the timed region.
+                 `achieved` = fp16-MFMA flops the kernel EXECUTES per launch / launch time, `peak` = 2500 TFLOP/s dense fp16 MFMA,
+                 `frac` <= 1 by construction. `algorithmic` = what the reference's dense fp32 iteration does for the same result
+                 (4 N^2 D iters flops per cloud) over the same time, and how much MFMA work the
+                 block-sparse schedule saves against the dense split kernel.
   one_weight_digit : the same step with fp16-head weights in the second product (5 instead of 6 MFMAs per block pair; opt-in:
                  ~0.2 % of a cloud's labels move against the reference, tests/test_gpu_baseline_configs.py).
   unstructured : round 1 / 2's headline workload, kept for continuity: closed-form weights whose embedding is ONE blob, so every
@@ -36,9 +36,12 @@ The JSON line also carries
                  two weight digits (fp32-equivalent) and once with one.
   hbm_frac     : algorithmic HBM bytes of the whole path / time / 8 TB/s (north_star asks for it; structurally low: the
                  dominant stage is a contraction whose operands live in LDS / L2).
-  cpu_baseline : the CPU oracle (numpy restatement of the reference path, oracle/) timed on this box's host cores
-                 (rank 0, N = 1 only): after a warm-up, median of 3 forwards / bandwidths / NMS / fits and all 50
-                 mean-shift iterations timed one by one. A reported baseline, not the target.
+  one_cloud    : ONE cloud per call, the reference script's own loop shape (generate_predictions_aug.py:178-180, :213
+                 batch_size = 1): end-to-end latency per cloud, median over the first 8 bench clouds, second pass.
+  cpu_baseline : the CPU oracle timed on this box's host cores (rank 0, N = 1 only): forwards and fits = the numpy restatement;
+                 the mean-shift stage on torch CPU tensors with all host threads, operation by operation as the reference writes
+                 it (its own path is torch; oracle/torch_cpu.py), all 50 iterations timed one by one, with the iteration's
+                 GFLOP/s and the numpy port's figure beside it. A reported baseline, not the target.
   ranks        : (N > 1) per-rank stage times, gather time and retry-balancing share, so that a scaling run explains itself.
 """
 import argparse
@@ -111,9 +114,12 @@ def _median_time(fn, n=3):
 
 
 def cpu_baseline(args):
-    """Oracle timed on the host, 1 cloud, the headline's trained weights: warm-up, then median of 3 for the forward / bandwidth /
-    NMS / fits and every one of the 50 mean-shift iterations timed (sum reported; the median iteration x 50 beside it)."""
-    from oracle import backbone, fit as ofit, mean_shift as oms
+    """The oracle timed on the host, 1 cloud, the headline's trained weights. Mean-shift stage (94 % of the reference's time) on torch
+    CPU tensors with torch.set_num_threads(cores) -- the reference's own path is torch: its elementwise exp / clamp / sum over the
+    N x N weight matrix run on the thread pool (oracle/torch_cpu.py, operation by operation as src/mean_shift.py writes it). The
+    numpy oracle (np.exp / np.clip on one thread) is timed on a few iterations beside it (`numpy_port`), so that both figures
+    and the host's GFLOP/s in the iteration are on the line. Forwards and fits: the numpy oracle (BLAS-threaded products)."""
+    from oracle import backbone, fit as ofit, mean_shift as oms, torch_cpu as otc
     from sednet_hip import synth
     cores = os.cpu_count() or 1
     N, k = args.points, args.k
@@ -128,24 +134,48 @@ def cpu_baseline(args):
     types = np.argmax(logp[0], 0)
     emb = backbone.sednet_forward(sd_i, x, k)[0][0].T                               # the instance model's forward (same cost)
     X = (emb / np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)).astype(np.float32)
-    t_bw, bw = _median_time(lambda: max(oms.compute_bandwidth(X, 10000, 0.015), np.float32(0.003)))
-    it_times, nx = [], X
-    for _ in range(args.iterations):
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        with torch.no_grad():
+            Xt = torch.from_numpy(X)
+            otc.mean_shift_step(torch.from_numpy(Xw), torch.from_numpy(Xw), 0.2)    # thread pool warm-up
+            t_bw, bw_t = _median_time(lambda: torch.clamp(otc.compute_bandwidth(Xt, 10000, 0.015), min=0.003))
+            bw = np.float32(bw_t.item())
+            it_times, nx = [], Xt
+            for _ in range(args.iterations):
+                t0 = time.perf_counter()
+                nx = otc.mean_shift_step(nx, Xt, bw_t)
+                it_times.append(time.perf_counter() - t0)
+            t_it = float(np.sum(it_times))
+            t_nms, (_, _, labels_t) = _median_time(lambda: otc.nms(nx, Xt, bw_t))
+        labels = labels_t.numpy()
+    finally:
+        torch.set_num_threads(threads0)
+    np_it, nxn = [], X
+    for _ in range(3):                                                              # the numpy port on 3 iterations (round 1-3's baseline)
         t0 = time.perf_counter()
-        nx = oms.mean_shift_step(nx, X, np.float32(bw))
-        it_times.append(time.perf_counter() - t0)
-    t_it = float(np.sum(it_times))
-    t_nms, (_, _, labels) = _median_time(lambda: oms.nms(nx, X, bw))
+        nxn = oms.mean_shift_step(nxn, X, bw)
+        np_it.append(time.perf_counter() - t0)
+    labels = np.unique(labels, return_inverse=True)[1]
     S = int(labels.max()) + 1
     seg_types = [int(np.bincount(types[labels == s], minlength=6).argmax()) for s in range(S)]
     t_fit, _ = _median_time(lambda: ofit.fit_segments_eval(p, n, labels, [t if t in (1, 3, 4, 5) else 1 for t in seg_types]))
     total = 2 * t_fwd + t_bw + t_it + t_nms + t_fit
+    total_np = 2 * t_fwd + t_bw + float(np.median(np_it)) * args.iterations + t_nms + t_fit
+    it_flops = 4.0 * N * N * X.shape[1]
     return {"value": round(1.0 / total, 5), "unit": "clouds/s", "cores": cores, "kind": "port",
-            "sample": f"1 cloud x {N} pts, k={k}, trained weights ({S} clusters), after a warm-up: oracle forward median of 3 = "
-                      f"{t_fwd:.2f}s (x2 models), bandwidth median of 3 = {t_bw:.2f}s, all {args.iterations} mean-shift "
-                      f"iterations timed one by one = {t_it:.1f}s (median iteration x {args.iterations} = "
-                      f"{float(np.median(it_times)) * args.iterations:.1f}s), nms median of 3 = {t_nms:.2f}s, fits = "
-                      f"{t_fit:.2f}s; numpy/BLAS threads = host cores"}
+            "iteration_gflops": round(it_flops / float(np.median(it_times)) / 1e9, 1),
+            "numpy_port": {"value": round(1.0 / total_np, 5), "unit": "clouds/s",
+                           "iteration_gflops": round(it_flops / float(np.median(np_it)) / 1e9, 1),
+                           "note": "rounds 1-3's baseline: np.exp / np.clip over the N x N matrix on one thread; median of 3 "
+                                   f"iterations x {args.iterations}"},
+            "sample": f"1 cloud x {N} pts, k={k}, trained weights ({S} clusters), after a warm-up: oracle forward (numpy / BLAS) median "
+                      f"of 3 = {t_fwd:.2f}s (x2 models); mean-shift stage on torch CPU tensors, {cores} threads, as the reference "
+                      f"writes it: bandwidth median of 3 = {t_bw:.2f}s, all {args.iterations} iterations timed one by one = "
+                      f"{t_it:.1f}s (median iteration {float(np.median(it_times)) * 1e3:.0f} ms = 4 N^2 d flops at "
+                      f"{it_flops / float(np.median(it_times)) / 1e9:.0f} GFLOP/s), nms median of 3 = {t_nms:.2f}s; fits (numpy) = "
+                      f"{t_fit:.2f}s"}
 
 
 def roofline_block(timers, N, iterations, digits, counters=None):
@@ -168,35 +198,49 @@ def roofline_block(timers, N, iterations, digits, counters=None):
     split = sparse or all(m.get("schedule") == "split-fp16" for _, m in it)
     mpp = mfma_per_product(digits)
     peak = F16_MFMA_PEAK_TFLOPS / mpp if split else FP32_MFMA_PEAK_TFLOPS
-    blk = {"kernel": ("ms_iterate_d128_f16s_kernel<true, %s, true, 4, %d>" % ("true" if digits == 2 else "false", D // 32)) if sparse else
-                     (("ms_iterate_f16w_kernel<%d, %s, %s>" % (D // 32, "true" if D == 160 else "false", "true" if digits == 2 else "false")) if split
-                      else "ms_iterate_d128_kernel"),
-           "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-           "traffic": None, "traffic_source": None, "avg_launch_ms": round(avg_ms, 3), "launches_per_step": None,
-           "clouds_per_launch": round(avg_clouds, 2), "embedding_width": D, "flops_per_launch": flops_per_cloud * avg_clouds,
-           "share_of_step": None,
-           "note": (f"achieved = ALGORITHMIC fp32 flops of the reference's dense iteration (4 N^2 d per cloud and iteration) / "
-                    f"launch time; the kernel evaluates every product as fp16 MFMAs on (h, l) splits ({mpp:g} MFMAs per product on "
-                    f"average with {digits} weight digit(s)), peak = 2500 / {mpp:g} TFLOP/s of algorithmic flops") if split else None}
+    from sednet_hip import _lib
+    if sparse:            # the instantiation that ran, as the library reports it (not composed here)
+        kname = _lib.lib.sed_ms_iterate_bounds_f16_kernel_name(D, digits).decode()
+    else:
+        kname = _lib.lib.sed_ms_iterate_kernel_name(int(round(avg_clouds)), N, D, ops._ms_options_for(it[0][1].get("forced"))).decode()
+    per_mfma = 2.0 * 32 * 32 * 16
+    # EXECUTED fp16-MFMA flops per launch: dense split kernels issue `mpp` MFMAs per algorithmic product over every (padded) 32 x 32
+    # block; the block-sparse kernel counts the first / second products its waves really run (device counters)
+    share = None
     if split and not sparse:
-        blk["executed_f16_mfma_tflops"] = round(mpp * ach, 1)
-        blk["executed_frac_of_f16_peak"] = round(mpp * ach / F16_MFMA_PEAK_TFLOPS, 4)
-        blk["x_fp32_mfma_peak"] = round(ach / FP32_MFMA_PEAK_TFLOPS, 3)
-    if sparse and counters is not None:
-        # device counters of the block-sparse kernel (accumulated over the timed region): [1] first products of waves,
-        # [2] second products of waves, [3] the dense count (stages x iterations per wave); a first product = 24 fp16 MFMAs of
-        # 32 x 32 x 16, a second product 24 (two weight digits) or 16
+        nb = (N + 31) // 32
+        ex_flops = mpp * 4.0 * (nb * 32) * (nb * 32) * D * iterations * avg_clouds
+    elif sparse and counters is not None and float(counters[3]) > 0:
         c = counters.cpu().numpy().astype(np.float64)
-        if c[3] > 0:
-            per_mfma = 2.0 * 32 * 32 * 16
-            ex_flops = (c[1] * 24 + c[2] * (24 if digits == 2 else 16)) * per_mfma
-            tot_ms = sum(t for t, _ in it)
-            blk["executed_share_of_dense_work"] = {"first_products": round(c[1] / c[3], 4), "second_products": round(c[2] / c[3], 4)}
-            blk["executed_f16_mfma_tflops"] = round(ex_flops / (tot_ms * 1e-3) / 1e12, 1)
-            blk["executed_frac_of_f16_peak"] = round(ex_flops / (tot_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4)
-            blk["note"] += (f"; block-sparse schedule: 32 x 32 blocks whose kernel weights are all <= e^{ops.MS_SPARSE_SKIP:g} = 2^-39 (what fp16(2^14 p) rounds to zero in the dense kernel too) are skipped (frac > 1 = "
-                            "work the reference does and this kernel proves negligible); executed_* = the MFMAs it really issues")
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_ms_iterate.json")
+        nmf = D // 16 * 3                                 # fp16 MFMAs of a block's first product ((h, l) x (h, l) without l l)
+        ex_flops = (c[1] * nmf + c[2] * (nmf if digits == 2 else nmf * 2 // 3)) * per_mfma / len(it)
+        share = {"first_products": round(c[1] / c[3], 4), "second_products": round(c[2] / c[3], 4)}
+    else:
+        ex_flops = None
+    if split and ex_flops is not None:
+        ach_ex = ex_flops / (avg_ms * 1e-3) / 1e12
+        blk = {"kernel": kname, "bound": "mfma", "achieved": round(ach_ex, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(ach_ex / F16_MFMA_PEAK_TFLOPS, 4),
+               "note": "achieved = fp16-MFMA flops the kernel EXECUTES per launch (dense: every padded 32 x 32 block x "
+                       f"{mpp:g} MFMAs per algorithmic product; block-sparse: the first / second products its waves run, device "
+                       "counters) / launch time measured with events on the launch stream; peak = dense fp16 MFMA. The work the "
+                       "reference's dense fp32 algorithm does for the same result is in `algorithmic`"}
+    else:
+        blk = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "note": "exact fp32 kernel: algorithmic flops on the fp32 matrix pipe"}
+    blk.update({"traffic": None, "traffic_source": None, "avg_launch_ms": round(avg_ms, 3), "launches_per_step": None,
+                "clouds_per_launch": round(avg_clouds, 2), "embedding_width": D, "share_of_step": None,
+                "algorithmic": {"flops_per_launch": flops_per_cloud * avg_clouds, "tflops": round(ach, 2),
+                                "x_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 3),
+                                "note": "4 N^2 d iterations flops per cloud (SURVEY.md section 8(d): the reference's dense "
+                                        "iteration) / launch time"}})
+    if split and ex_flops is not None:
+        blk["algorithmic"]["speedup_vs_dense_split_kernel_work"] = round(mpp * flops_per_cloud * avg_clouds / ex_flops, 3)
+    if share is not None:
+        blk["executed_share_of_dense_work"] = share
+        blk["note"] += (f"; block-sparse schedule: 32 x 32 blocks whose kernel weights are all <= e^{ops.MS_SPARSE_SKIP:g} = 2^-39 "
+                        "(what fp16(2^14 p) rounds to zero in the dense kernel too) are skipped")
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_ms_iterate.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec.get("kernel", "").split("<")[0] == blk["kernel"].split("<")[0] and rec.get("clouds") == int(avg_clouds):
@@ -422,6 +466,23 @@ def main():
             hp_sum["x_headline_time_per_cloud"] = round(hp_sum["ms_per_step"] / head_sum["ms_per_step"], 3)
             line["hpnet"] = hp_sum
             del pipe_h
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # ---- one cloud per call: how the reference script itself runs (batch_size = 1)
+        n1 = min(8, x.shape[0])
+        ts = []
+        for rep in range(2):
+            for i in range(n1):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                pipe(x[i:i + 1])
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+        t1c = np.array(ts[n1:]) * 1e3                      # second pass: warm
+        line["one_cloud"] = {"value": round(1e3 / float(np.median(t1c)), 2), "unit": "clouds/s",
+                             "ms_per_cloud": {"median": round(float(np.median(t1c)), 2), "min": round(float(t1c.min()), 2),
+                                              "max": round(float(t1c.max()), 2)},
+                             "note": f"one cloud per call (the reference's loop shape), the first {n1} bench clouds one after the "
+                                     "other, host-synchronised per cloud; same kernels and schedule per cloud as in the batch"}
     if rank == 0:
         if world == 1 and args.k != 64 and not args.no_k64:
             # also report the reference's default neighbourhood size k = 64 (same clouds, same path)

@@ -122,20 +122,19 @@ int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const fl
  *   summation orders sit from each other (5e-5 on a trained network's 10 000-point embedding), labels equal the reference's up to
  *   true ties; 1 = fp16 heads only, consistently in numerator and row sum (5 MFMAs, 14 % faster; rows within 8e-4 on the same
  *   embedding, 0.2 % of the labels move; clouds in which a weighted mean nearly cancels are flagged on the device and redone with
- *   2 digits).
- * wave_queries: query rows per wave of the split-fp16 dense kernel: 0 = default, 32 = 8-wave workgroups (two waves per SIMD,
- *   256 registers each), 64 = 4-wave workgroups (one wave per SIMD with the whole 512-register file: every key operand read
- *   from LDS feeds two query groups). Same MFMA order per accumulator: the two forms return the same bits. */
+ *   2 digits). */
 typedef struct sed_ms_options {
     int schedule;
     int weight_digits;
-    int wave_queries;
 } sed_ms_options_t;
 /* Same, with a caller-owned workspace of sed_ms_iterate_workspace_bytes(B, N, d, opt) bytes (0 = none needed). */
 size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options_t* opt);
 /* the schedule sed_ms_iterate_ws_f32 takes for this shape and these options when given that workspace (values as
  * sed_ms_options_t.schedule, 1 .. 5); 0 = unsupported shape or options */
 int sed_ms_iterate_plan(int B, int N, int d, const sed_ms_options_t* opt);
+/* the kernel (template instantiation, as a profiler prints it) that does the iterations of such a call: a static string, "" if the
+ * shape / options are unsupported. For measurement records (bench.py's roofline.kernel); not part of the reference's surface. */
+const char* sed_ms_iterate_kernel_name(int B, int N, int d, const sed_ms_options_t* opt);
 int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                           void* workspace, size_t workspace_bytes, const sed_ms_options_t* opt, sed_stream_t stream);
 /* Farthest-point pivot rows for the row order of the block-sparse schedule: greedy k-centre on the unit sphere among rows
@@ -143,38 +142,37 @@ int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float* bw, const
  * row 0), picked [B,P,128] those rows. d = 128. */
 int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, int* picks, float* picked,
                        sed_stream_t stream);
-/* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_iterate_d128_f16s_kernel): identical
+/* Block-sparse schedule with the products on the fp16 matrix pipe (split-fp16, ms_sparse_f16.hip: ms_sparse_f16_kernel): identical
  * arithmetic, except that 32 x 32 (keys x queries) blocks in which every kernel weight is provably <= e^skip_below are skipped;
  * a row sum (>= 1, the self weight) changes by <= N e^skip_below relative. The Python mirror passes skip_below = -27.04 = ln 2^-39:
  * a weight below 2^-39 rounds to zero when the split-fp16 kernels convert 2^14 p to fp16 -- in the dense kernel too --, so that
  * value drops exactly what the dense kernel cannot represent (N 2^-39 = 1.8e-8 at N = 10 000). Between mask rebuilds a wave also
- * leaves out the first product of a block all of whose weights are provably below that point until the next rebuild. X: unit rows sorted so that 32-row tiles are cluster-pure (any
- * order is correct; the order decides how much is skipped). Every tile t
- * has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
- * split) -- stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128], nref = sed_ms_iterate_bounds_f16_refs(N),
+ * leaves out the first product of a block all of whose weights are provably below that point until the next rebuild.
+ * X: unit rows sorted so that 32-row tiles are cluster-pure (any order is correct; the order decides how much is skipped). Every
+ * tile t has TWO unit reference vectors -- normalised means of two groups of its rows (before / after a cluster border, or any
+ * split) -- stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, d], nref = sed_ms_iterate_bounds_f16_refs(N),
  * unused rows zero; tile_cosalpha [B, nref]: the smallest dot product of a row of the group with its reference. Every
- * iteration every wave measures its 32 queries against all references on the matrix pipe and skips the blocks with
- * angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for all its queries and both references. workspace: stage
- * images of rows and references; stats: NULL or 5 device uint64 counters that are ADDED to (stage visits of workgroups,
- * first products of waves, second products of waves, stages x iterations per wave = the dense count, mask / list
- * constructions of workgroups -- they are rebuilt only after a query has turned by more than 0.005 rad). weight_digits: as in
- * sed_ms_options_t. form: 0 = default (5); 1 = 8-wave workgroups of 32-query waves on four-plane stage images (37 KiB per 32 keys),
- * a wave skips the blocks it does not need (round 2's kernel); 4 = the same kernel on row-major stage images (17 KiB: half the
- * L2 / fabric traffic, second-product operands by LDS transpose reads); 5 = form 4 with 4-wave workgroups (128 query rows, two
- * workgroups per CU: smaller unions of the waves' stage lists, two independent barrier domains); 2 / 3 = 64 queries per wave on
- * row-major images with 2- / 4-wave workgroups, all waves of a workgroup compute every listed stage on the dense kernel's software
- * pipeline (more MFMAs, fewer stalls: slower on a power-limited chip, kept selectable). All forms skip by the same rule (rows differ
- * by summation order only) and run as PERSISTENT workgroups: a first launch builds every work item's first stage list and reports
- * its length; the items are then queued per XCD -- whole clouds, heaviest first, a cloud's items longest first -- and the resident
- * workgroups take items from their XCD's queue (then from the others') through atomic counters in the workspace. Clouds whose rows
- * are not unit vectors run the exact dense fp32 kernel. N <= 16 384; d = 128, or 160 (rows padded from the HPNet flow's 140
- * columns; default form only); iters = 0 copies the rows. */
+ * iteration in which a query has turned by more than 0.005 rad since the last time, every wave measures its 32 queries against
+ * all references on the matrix pipe and skips the blocks with angle(q, ref) - alpha >= acos(1 + skip_below b^2) + margin for all
+ * its queries and both references. workspace: stage images of rows and references + work queues; stats: NULL or 5 device uint64
+ * counters that are ADDED to (stage visits of workgroups, first products of waves, second products of waves, stages x iterations
+ * per wave = the dense count, mask constructions of workgroups). weight_digits: as in sed_ms_options_t.
+ * One work item = 128 query rows of a cloud for all iterations, run by PERSISTENT 4-wave workgroups (two per CU): a first launch
+ * builds every item's first stage list and reports its length; the items are then queued per XCD -- whole clouds, heaviest first
+ * -- and the resident workgroups take items from their XCD's queue (then from the others') through atomic counters in the
+ * workspace. form: 0 = a cloud's items longest first (default); 1 = in row order (neighbouring items = queries of the same
+ * clusters run at the same time: a smaller working set per L2). An item's result does not depend on any other item: a cloud's
+ * rows are the same bits whatever else is in the call and whichever form queues it. Clouds whose rows are not unit vectors run
+ * the exact dense fp32 kernel. N <= 16 384; d = 128, or 160 (rows padded from the HPNet flow's 140 columns); iters = 0 copies
+ * the rows. */
 int sed_ms_iterate_bounds_f16_refs(int N);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);
 int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
                                   float skip_below, const float* tile_ref, const float* tile_cosalpha, float margin,
                                   void* workspace, size_t workspace_bytes, void* stats, int weight_digits, int form,
                                   sed_stream_t stream);
+/* the kernel instantiation that runs the iterations of such a call (static string; "" if unsupported) */
+const char* sed_ms_iterate_bounds_f16_kernel_name(int d, int weight_digits);
 /* Preparation of the block-sparse schedule, all on the device (ms_sparse_prep.hip): P <= 64 farthest-point pivots among every
  * stride-th row, one k-means step, single-linkage super-groups of the means (merge_angle, radians), rows stable-sorted by
  * (super-group, group) -> order [B,N] (sorted position -> row), Xs [B,N,128] the rows in that order, and per 32-row tile two

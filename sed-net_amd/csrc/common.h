@@ -93,6 +93,23 @@ __device__ __forceinline__ float sed_vmax(float a, float b) {
 // max(a, b) as one instruction the compiler knows.
 __device__ __forceinline__ float sed_vmax_acc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 
+
+// A kernel's dynamic-LDS limit must be raised once PER DEVICE before its first launch there (hipFuncSetAttribute). The launchers
+// remember which devices have seen the call in a function-local bit set (written atomically; the call is idempotent, so a race
+// between host threads only repeats it). Not behaviour: nothing a caller can observe depends on it.
+#include <atomic>
+static inline bool sed_first_on_device(std::atomic<unsigned long long>& seen, int* err) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    *err = e == hipSuccess ? 0 : (int)e;
+    if (e != hipSuccess) return false;
+    return dev >= 64 || !((seen.load(std::memory_order_relaxed) >> dev) & 1ull);
+}
+static inline void sed_mark_device(std::atomic<unsigned long long>& seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev < 64) seen.fetch_or(1ull << dev, std::memory_order_relaxed);
+}
+
 static inline int sed_pad_dim(int d) {      // feature width the MFMA kernels are instantiated for
     if (d <= 32) return 32;
     if (d <= 64) return 64;

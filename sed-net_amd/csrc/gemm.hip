@@ -214,13 +214,14 @@ extern "C" int sed_gemm_f32(int M, int N, int K, const float* A, int lda, int tr
         gemm_kernel<true><<<grid, 256, sm, stream>>>(A, lda, transA, B, ldb, transB, dst, ldo, M, N, K, kchunk, stride);
     } else {
         const size_t sm = 2 * 2 * 128 * 33 * 4;
-        static bool attr = false;
-        if (!attr) {
+        static std::atomic<unsigned long long> attr{0};      // devices whose limit has been raised (common.h)
+        int attr_err = 0;
+        if (sed_first_on_device(attr, &attr_err)) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sm);
             if (e != hipSuccess) return (int)e;
-            attr = true;
-        }
+            sed_mark_device(attr);
+        } else if (attr_err) return attr_err;
         gemm_kernel<false><<<grid, 256, sm, stream>>>(A, lda, transA, B, ldb, transB, dst, ldo, M, N, K, kchunk, stride);
     }
     SED_LAUNCH_CHECK();

@@ -867,6 +867,22 @@ extern "C" int sed_ms_iterate_plan(int B, int N, int d, const sed_ms_options* op
     return ms_plan(B, N, d, true, true, opt_schedule(opt));
 }
 
+extern "C" const char* sed_ms_iterate_kernel_name(int B, int N, int d, const sed_ms_options* opt) {
+    if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0 || !opt_valid(opt)) return "";
+    switch (ms_plan(B, N, d, true, true, opt_schedule(opt))) {
+        case MS_F16: return ms_f16_kernel_name(d, d == 160, opt_digits(opt));     // d = 160: whole sweeps through the chunked form
+        case MS_F16_CHUNKED: return ms_f16_kernel_name(d, true, opt_digits(opt));
+        case MS_CHUNKED: return d == 128 ? "ms_partial_d128_kernel" : "ms_partial_kernel";
+        case MS_SPLITK: return "ms_iterate_d128_splitk_kernel";
+        default: return d == 128 ? "ms_iterate_d128_kernel" : "ms_iterate_kernel";
+    }
+}
+
+extern "C" const char* sed_ms_iterate_bounds_f16_kernel_name(int d, int weight_digits) {
+    if ((d != 128 && d != 160) || weight_digits < 0 || weight_digits > 2) return "";
+    return ms_f16_sparse_kernel_name(d, weight_digits == 1 ? 1 : 2);
+}
+
 extern "C" size_t sed_ms_iterate_workspace_bytes(int B, int N, int d, const sed_ms_options* opt) {
     if (d % 32 != 0 || d < 32 || d > 160 || B <= 0 || N <= 0 || !opt_valid(opt)) return 0;
     const int plan = ms_plan(B, N, d, true, true, opt_schedule(opt));
@@ -909,13 +925,14 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
         // clouds whose rows are not unit vectors (flag set by the split kernel) were skipped: exact fp32 pass for them;
         // its workgroups return at once for every other cloud
         constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
-        static bool attr_fb = false;
-        if (!attr_fb) {
+        static std::atomic<unsigned long long> attr_fb{0};      // devices whose limit has been raised (common.h)
+        int attr_fb_err = 0;
+        if (sed_first_on_device(attr_fb, &attr_fb_err)) {
             hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm);
             if (e != hipSuccess) return (int)e;
-            attr_fb = true;
-        }
+            sed_mark_device(attr_fb);
+        } else if (attr_fb_err) return attr_fb_err;
         if (d == 160) ms_iterate_kernel<5><<<grid, block, 0, stream>>>(X, newX, bw, N, iters, flags);
         else ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
         SED_LAUNCH_CHECK();
@@ -928,13 +945,14 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
         const dim3 pgrid(S, (N + 127) / 128, B);
         constexpr int smc = 2 * 64 * 132 * (int)sizeof(float);
         if (d == 128) {
-            static bool attr_c = false;
-            if (!attr_c) {
+            static std::atomic<unsigned long long> attr_c{0};      // devices whose limit has been raised (common.h)
+            int attr_c_err = 0;
+            if (sed_first_on_device(attr_c, &attr_c_err)) {
                 hipError_t e = hipFuncSetAttribute((const void*)ms_partial_d128_kernel,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, smc);
                 if (e != hipSuccess) return (int)e;
-                attr_c = true;
-            }
+                sed_mark_device(attr_c);
+            } else if (attr_c_err) return attr_c_err;
         }
         for (int it = 0; it < iters; ++it) {
             const float* Q = it == 0 ? X : newX;
@@ -957,24 +975,26 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
         case 4: {
             if (plan == MS_SPLITK) {
                 constexpr int smk = 8 * 32 * 132 * (int)sizeof(float);     // 132 KiB
-                static bool attr_k = false;
-                if (!attr_k) {
+                static std::atomic<unsigned long long> attr_k{0};      // devices whose limit has been raised (common.h)
+                int attr_k_err = 0;
+                if (sed_first_on_device(attr_k, &attr_k_err)) {
                     hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_splitk_kernel,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, smk);
                     if (e != hipSuccess) return (int)e;
-                    attr_k = true;
-                }
+                    sed_mark_device(attr_k);
+                } else if (attr_k_err) return attr_k_err;
                 ms_iterate_d128_splitk_kernel<<<dim3((N + 31) / 32, B), 512, smk, stream>>>(X, newX, bw, N, iters);
                 break;
             }
             constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);          // 66 KiB of dynamic LDS: opt in once
-            static bool attr_set = false;
-            if (!attr_set) {
+            static std::atomic<unsigned long long> attr_set{0};      // devices whose limit has been raised (common.h)
+            int attr_set_err = 0;
+            if (sed_first_on_device(attr_set, &attr_set_err)) {
                 hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, sm);
                 if (e != hipSuccess) return (int)e;
-                attr_set = true;
-            }
+                sed_mark_device(attr_set);
+            } else if (attr_set_err) return attr_set_err;
             ms_iterate_d128_kernel<false><<<grid, block, sm, stream>>>(X, newX, bw, N, iters, 0.f);
             break;
         }
@@ -984,7 +1004,7 @@ extern "C" int sed_ms_iterate_ws_f32(int B, int N, int d, int iters, const float
     return SED_OK;
 }
 
-// ---- block-sparse split-fp16 schedule (ms_iterate_f16.hip: ms_iterate_d128_f16s_kernel) ------------------------------
+// ---- block-sparse split-fp16 schedule (ms_sparse_f16.hip: ms_sparse_f16_kernel) --------------------------------------
 // X [B,N,128]: unit rows sorted so that 32-row tiles are cluster-pure (any order is CORRECT; the order decides how much can
 // be skipped); every tile t has two unit reference vectors (normalised means of two groups of its rows -- the rows before
 // and after a cluster border, or any split), stored as row (2 (t / 32) + w) 32 + t % 32 of tile_ref [B, nref, 128],
@@ -1025,13 +1045,14 @@ extern "C" int sed_ms_iterate_bounds_f16_f32(int B, int N, int d, int iters, con
         return SED_OK;
     }
     constexpr int sm = 2 * 64 * 132 * (int)sizeof(float);
-    static bool attr_fb = false;
-    if (!attr_fb) {
+    static std::atomic<unsigned long long> attr_fb{0};      // devices whose limit has been raised (common.h)
+    int attr_fb_err = 0;
+    if (sed_first_on_device(attr_fb, &attr_fb_err)) {
         hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_d128_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
-        attr_fb = true;
-    }
+        sed_mark_device(attr_fb);
+    } else if (attr_fb_err) return attr_fb_err;
     ms_iterate_d128_kernel<false><<<dim3((N + 127) / 128, B), 256, sm, stream>>>(X, newX, bw, N, iters, 0.f, flags);
     SED_LAUNCH_CHECK();
     return SED_OK;

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void ms_iterate_f16w_kernel(const float* __
 // ---- entry points used by ms_iterate.hip's planner ----------------------------------------------------------
 // `digits` = fp16 digits of the kernel weights in the second product (sed_ms_options_t.weight_digits): 1 = fp16 heads, clouds whose
 // weighted means cancel redone with (h, l) weights by a second launch; 2 = (h, l) weights everywhere. No state is kept between
-// calls: the dynamic-LDS limit of a kernel is raised on every call (idempotent, per device, microseconds).
+// calls (the function-local bit sets only remember on which devices a kernel's dynamic-LDS limit has been raised: common.h).
 
 static size_t f16_flag_bytes(int B) { return (((size_t)B * sizeof(int) + 255) / 256) * 256; }
 static size_t f16_blob_bytes_n(int B, int N, int d) {                                      // row-major images
@@ -465,9 +465,14 @@ template <int NT, bool CHUNKED, bool PL>
 static int f16w_one(dim3 grid, const float* X, const uint8_t* blob, float* newX, const float* bw, const int* flags, int N, int iters,
                     const float* Q, float* partO, float* partS, int* lowq, hipStream_t stream) {
     constexpr int sm = 3 * StageLayoutD<NT>::STAGE;
-    const hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, CHUNKED, PL>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
+    static std::atomic<unsigned long long> attr{0};      // devices whose limit has been raised (common.h)
+    int attr_err = 0;
+    if (sed_first_on_device(attr, &attr_err)) {
+        const hipError_t e = hipFuncSetAttribute((const void*)ms_iterate_f16w_kernel<NT, CHUNKED, PL>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        sed_mark_device(attr);
+    } else if (attr_err) return attr_err;
     ms_iterate_f16w_kernel<NT, CHUNKED, PL><<<grid, 256, sm, stream>>>(X, blob, newX, bw, flags, N, iters, Q, partO, partS, lowq);
     return SED_OK;
 }

@@ -679,9 +679,15 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
     constexpr int NW = F16S_NW;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     constexpr int sm = (NT == 4 ? 4 : 3) * StageLayoutD<NT>::STAGE;
-    hipError_t e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    static std::atomic<unsigned long long> attr{0};      // devices whose limit has been raised (common.h)
+    int attr_err = 0;
+    if (sed_first_on_device(attr, &attr_err)) {
+        e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ms_sparse_f16_kernel<false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        if (e != hipSuccess) return (int)e;
+        sed_mark_device(attr);
+    } else if (attr_err) return attr_err;
     const int nbx = (N + 32 * NW - 1) / (32 * NW), nitems = nbx * B;
     if (nbx > 255 || B > (1 << 22)) return SED_EUNSUPPORTED;
     int dev = 0, slots = 0;                                // resident workgroups: 8 waves of 256 registers per CU

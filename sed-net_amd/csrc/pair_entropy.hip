@@ -244,13 +244,14 @@ extern "C" int sed_pair_entropy_mfma_f32(int M, const void* split, int mode, flo
     const float* n2 = (const float*)((const uint8_t*)split + (size_t)M * 2 * PE_K * sizeof(h16));
     const int nb = (M + 127) / 128;
     constexpr int sm = 2 * 2 * 128 * (2 * PE_K + 16);           // 139 264 B of stage planes
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned long long> attr{0};      // devices whose limit has been raised (common.h)
+    int attr_err = 0;
+    if (sed_first_on_device(attr, &attr_err)) {
         hipError_t e = hipFuncSetAttribute((const void*)pair_entropy_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pair_entropy_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+        sed_mark_device(attr);
+    } else if (attr_err) return attr_err;
     // (the caller sums sed_pair_entropy_partials(M) entries: this kernel fills the upper triangle of the first nb x nb)
     hipError_t e = hipMemsetAsync(partials, 0, sed_pair_entropy_partials(M) * sizeof(double), stream);
     if (e != hipSuccess) return (int)e;

@@ -559,16 +559,17 @@ static int pointwise_fwd(int B, int N, int K, int Coutp, int Cout, const float* 
     if ((flags & F_COLEXT) && !colext) return SED_EINVAL;
     const int nblk = (N + 127) / 128;
     if (Coutp % 128 == 0) {
-        static bool attr_set = false;      // > 64 KiB of dynamic LDS needs the opt-in once per process
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};      // devices whose limit has been raised (common.h)
+        int attr_set_err = 0;
+        if (sed_first_on_device(attr_set, &attr_set_err)) {
             hipError_t e = hipFuncSetAttribute((const void*)pointwise_kernel<4, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return (int)e;
             e = hipFuncSetAttribute((const void*)pointwise_kernel<4, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+            sed_mark_device(attr_set);
+        } else if (attr_set_err) return attr_set_err;
         const size_t sm = (2 * 128 * 36 + 2 * 32 * 128) * sizeof(float) + 4 * 4 * 2 * sizeof(double) + 4 * 128 * 2 * sizeof(float);
         if (bf16)
             pointwise_kernel<4, true><<<dim3(nblk, B, Coutp / 128), 256, sm, stream>>>(
@@ -638,13 +639,14 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
         return (size_t)(2 * 3 * BN * 40) * sizeof(__bf16) + 4 * TN * 2 * sizeof(double) + 4 * BN * 2 * sizeof(float);
     };
     if (Coutp % 128 == 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};      // devices whose limit has been raised (common.h)
+        int attr_set_err = 0;
+        if (sed_first_on_device(attr_set, &attr_set_err)) {
             hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+            sed_mark_device(attr_set);
+        } else if (attr_set_err) return attr_set_err;
         pointwise_split_kernel<4><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags);

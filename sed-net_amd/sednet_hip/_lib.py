@@ -19,7 +19,7 @@ P = c_void_p  # every device pointer / stream travels as void*
 
 class MsOptions(ctypes.Structure):
     """sed_ms_options_t (include/sednet_hip.h): per-call options of the mean-shift iteration entry points."""
-    _fields_ = [("schedule", c_int), ("weight_digits", c_int), ("wave_queries", c_int)]
+    _fields_ = [("schedule", c_int), ("weight_digits", c_int)]
 
 
 OPT = ctypes.POINTER(MsOptions)
@@ -53,6 +53,8 @@ SIGNATURES = {
     "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, c_int, P]),
     "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int, OPT]),
     "sed_ms_iterate_plan": (c_int, [c_int, c_int, c_int, OPT]),
+    "sed_ms_iterate_kernel_name": (ctypes.c_char_p, [c_int, c_int, c_int, OPT]),
+    "sed_ms_iterate_bounds_f16_kernel_name": (ctypes.c_char_p, [c_int, c_int]),
     "sed_ms_iterate_ws_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, OPT, P]),
     "sed_fps_pivots_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_iterate_bounds_f16_refs": (c_int, [c_int]),

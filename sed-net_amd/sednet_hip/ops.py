@@ -233,11 +233,14 @@ def ms_bandwidth(X, K, min_bw=0.003):
     return bw
 
 
-# Block-sparse mean-shift schedule (d = 128, ms_iterate_sparse): "auto" = per cloud, by a density probe (ms_near_fraction:
+# Block-sparse mean-shift schedule (d = 128 / 160, ms_iterate_sparse): "auto" = per cloud, by a density probe (ms_near_fraction:
 # the share of sampled row pairs whose kernel weight exceeds e^MS_SPARSE_SKIP; clustered embeddings -- what a trained
-# network produces -- sit near 1 / #clusters, unstructured ones near 1); "on" / "off" force it. The probe is a function of the
-# cloud alone; the SCHEDULE also depends on the batch (one cloud per call, or a single structured cloud among unstructured ones,
-# runs the dense kernels: 40 work items cannot fill 256 CUs) -- rows then differ by the summation order, ms_set_variant pins it.
+# network produces -- sit near 1 / #clusters, unstructured ones near 1); "on" / "off" force it. Probe AND schedule are functions
+# of the cloud alone (round 4): a structured cloud runs the block-sparse kernel whether it is alone in the call, one of two or one
+# of 64 (its work items are independent of every other cloud's), an unstructured one the key-chunked dense kernel in launches of
+# at most MS_DENSE_GROUP clouds (its chunk count depends on N only) -- so rows, and the labels behind them, do not depend on
+# --batch or on the number of ranks. (Rounds 2 / 3 sent a cloud that was alone in its call to the dense kernel: 7.0 against
+# 9.1 ms at one cloud per call, paid with labels that moved with the batch size; ms_set_variant still pins any schedule.)
 MS_SPARSE = "auto"
 # Blocks whose kernel weights are all <= e^MS_SPARSE_SKIP are skipped. -27.04 = ln 2^-39: a weight below 2^-39 becomes 0 when
 # the split-fp16 kernels round 2^14 p to fp16 (round to nearest even: 2^-25 and below -> 0), in the dense kernel too -- the sparse
@@ -251,14 +254,14 @@ MS_SPARSE_SKIP = -27.04
 # kernel could win on the widest clouds (134 + 177 ms against 249 ms for all 64 sparse). Unstructured rows sit at 1.0.
 MS_SPARSE_MAX_NEAR = 0.6
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
-MS_SPARSE_FORM = 0              # kernel form of the block-sparse schedule: 0 = library default, 1 = round 2's, 2 / 3 = round 3's
+MS_DENSE_GROUP = 16             # clouds per launch of the key-chunked dense kernel (where the planner's cost model puts the break-even)
+MS_SPARSE_FORM = 0              # item queueing of the block-sparse kernel: 0 = a cloud's items longest first, 1 = in row order (same bits)
 MS_SPARSE_COUNTERS = None       # bench.py: an int64 [5] device tensor the block-sparse kernel adds its visit counts to
 # Options of the iteration kernels. They are the WRAPPER's state, handed to the library with every call (sed_ms_options_t);
 # libsedhip.so itself keeps none. CONFIG_EPOCH counts changes of any kernel-selection switch of this module, so that
 # captured HIP graphs (pipeline.py) can be keyed on it.
 _MS_VARIANT = "auto"
 _MS_WEIGHT_DIGITS = 2
-MS_WAVE_QUERIES = 0      # query rows per wave of the dense split-fp16 kernel: 0 = library default, 32, 64 (same bits)
 CONFIG_EPOCH = 0
 _MS_SCHEDULES = {"auto": 0, "batched": 1, "splitk": 2, "chunked": 3, "f16": 4, "f16c": 5}
 
@@ -269,7 +272,12 @@ def config_changed():
 
 
 def _ms_options():
-    return _lib.MsOptions(_MS_SCHEDULES[_MS_VARIANT], _MS_WEIGHT_DIGITS, MS_WAVE_QUERIES)
+    return _lib.MsOptions(_MS_SCHEDULES[_MS_VARIANT], _MS_WEIGHT_DIGITS)
+
+
+def _ms_options_for(schedule=None):
+    """the options a dense call with this forced schedule (None: the module's current choice) passes to the library"""
+    return _ms_options() if schedule is None else _lib.MsOptions(_MS_SCHEDULES[schedule], _MS_WEIGHT_DIGITS)
 
 
 def ms_set_weight_digits(digits):
@@ -372,38 +380,43 @@ def ms_iterate(X, bw, iters):
     if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D in (128, 160) and iters > 0 and 1024 <= N <= 16384:
         if MS_SPARSE == "on":
             return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
-        if B == 1:
-            # one cloud per call (how the reference script runs): its 40 workgroups leave the block-sparse kernel one round
-            # of 7.4 ms + 1.7 ms of preparation on 16 % of the CUs, the key-chunked dense schedule takes 7.0 ms on all of them
-            # (tools/one_cloud_profile.sh) -- and the density probe with its D->H copy is not needed at all
-            MS_SPARSE_STATS["dense_clouds"] += 1
-            return _ms_iterate_dense(X, bw, iters)
         sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < MS_SPARSE_MAX_NEAR).cpu()       # one small D->H copy
         ns = int(sparse.sum())
-        if ns == 1:                                 # a single clustered cloud in the batch: the same argument
-            sparse[:] = False
-            ns = 0
         MS_SPARSE_STATS["sparse_clouds"] += ns
         MS_SPARSE_STATS["dense_clouds"] += B - ns
         if ns == B:
             return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
-        if ns > 0:
-            si = torch.nonzero(sparse).squeeze(1).to(X.device)
-            di = torch.nonzero(~sparse).squeeze(1).to(X.device)
-            out = torch.empty_like(X)
-            out[si] = ms_iterate_sparse(X[si], bw[si].contiguous(), iters, MS_SPARSE_SKIP)
-            out[di] = _ms_iterate_dense(X[di], bw[di].contiguous(), iters)
-            return out
+        if ns == 0:
+            return _ms_iterate_dense_by_cloud(X, bw, iters)
+        si = torch.nonzero(sparse).squeeze(1).to(X.device)
+        di = torch.nonzero(~sparse).squeeze(1).to(X.device)
+        out = torch.empty_like(X)
+        out[si] = ms_iterate_sparse(X[si], bw[si].contiguous(), iters, MS_SPARSE_SKIP)
+        out[di] = _ms_iterate_dense_by_cloud(X[di], bw[di].contiguous(), iters)
+        return out
     return _ms_iterate_dense(X, bw, iters)
 
 
-def _ms_iterate_dense(X, bw, iters):
+def _ms_iterate_dense_by_cloud(X, bw, iters):
+    """The dense split-fp16 schedule as a function of the cloud alone: always the key-chunked form (chunk count = f(N)), at most
+    MS_DENSE_GROUP clouds per launch -- the same bits for a cloud whatever else is in the batch."""
+    B = X.shape[0]
+    if B <= MS_DENSE_GROUP:
+        return _ms_iterate_dense(X, bw, iters, schedule="f16c")
+    out = torch.empty_like(X)
+    for b0 in range(0, B, MS_DENSE_GROUP):
+        out[b0:b0 + MS_DENSE_GROUP] = _ms_iterate_dense(X[b0:b0 + MS_DENSE_GROUP], bw[b0:b0 + MS_DENSE_GROUP].contiguous(), iters,
+                                                        schedule="f16c")
+    return out
+
+
+def _ms_iterate_dense(X, bw, iters, schedule=None):
     B, N, D = X.shape
     out = torch.empty_like(X)
     if TIMERS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    opt = _ms_options()
+    opt = _ms_options_for(schedule)
     nws = lib.sed_ms_iterate_workspace_bytes(B, N, D, opt)      # split-fp16 stage images (d = 128) / key-chunked partials
     ws = torch.empty((nws,), dtype=torch.uint8, device=X.device) if nws else None
     check(lib.sed_ms_iterate_ws_f32(B, N, D, int(iters), ptr(bw), ptr(X), ptr(out), ptr(ws) if nws else None, nws,
@@ -411,7 +424,7 @@ def _ms_iterate_dense(X, bw, iters):
     if TIMERS is not None:
         ev1.record()
         plan = lib.sed_ms_iterate_plan(B, N, D, opt) if nws else 1
-        TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters),
+        TIMERS.append(("ms_iterate", ev0, ev1, {"B": B, "N": N, "D": D, "iters": int(iters), "forced": schedule,
                                                 "schedule": "split-fp16" if plan in (4, 5) else "fp32"}))
     return out
 

@@ -111,8 +111,8 @@ class MeanShift:
                                dist=None):
         """Batched form of the script-level guard loop (generate_predictions_aug.py:25-35): every cloud
         whose label count exceeds `max_clusters` is re-run with its own quantile *= factor -- as further passes over
-        ONLY those clouds. With `dist` (an initialised torch.distributed, world > 1) the retry passes are collective and
-        spread over all ranks (sednet_hip.shard.balanced_guard_retries); every rank must then call this method.
+        ONLY those clouds. With `dist` (an initialised torch.distributed; a world of one rank takes the same path) the retry passes
+        are collective and spread over all ranks (sednet_hip.shard.balanced_guard_retries); every rank must then call this method.
         -> (labels [B,N] i32, bw [B], n_labels [B] i32 (host), passes [B] (host))."""
         B = X.shape[0]
         q = np.full(B, float(quantile))
@@ -138,7 +138,7 @@ class MeanShift:
                     lab[sel], b[sel], nl[sel] = lab_g, bw_g, nl_g.long()
             return lab, b, nl
 
-        distributed = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = dist is not None and dist.is_initialized()
         todo = np.arange(B)
         first = True
         while distributed or todo.size:

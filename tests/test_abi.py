@@ -61,15 +61,17 @@ def test_identity_and_argument_validation(lib):
 
 def test_library_keeps_no_mutable_global_state(lib):
     """"re-entrant; no global state". No process-wide setter is exported, and no kernel source keeps a
-    mutable global that a call could leave behind (function-local `static bool attr` flags only remember that a kernel's
-    dynamic-LDS limit has been raised -- idempotent, not behaviour)."""
+    mutable global that a call could leave behind (function-local per-device bit sets only remember on which devices a kernel's
+    dynamic-LDS limit has been raised -- idempotent, not behaviour: csrc/common.h) and no process-wide `static bool` / `static int`
+    cache is left in a launcher (they were per process, not per device)."""
     assert not [n for n in declared() if "_set_" in n]
     bad = []
     csrc = os.path.join(ROOT, "sed-net_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".hip", ".h")):
             for i, line in enumerate(open(os.path.join(csrc, f)), 1):
-                if re.match(r"^(static\s+)?(int|float|bool|unsigned|size_t)\s+g_\w+", line):
+                if re.match(r"^(static\s+)?(int|float|bool|unsigned|size_t)\s+g_\w+", line) or \
+                        re.match(r"^\s+static\s+(bool|int)\s+\w+\s*=", line):
                     bad.append(f"{f}:{i}: {line.strip()}")
     assert not bad, bad
     # options travel per call: a NULL options pointer means defaults, an out-of-range schedule is rejected
@@ -79,6 +81,11 @@ def test_library_keeps_no_mutable_global_state(lib):
     assert _lib.lib.sed_ms_iterate_plan(64, 10000, 128, _lib.MsOptions(1, 0)) == 1
     assert _lib.lib.sed_ms_iterate_plan(64, 10000, 128, _lib.MsOptions(9, 0)) == 0
     assert _lib.lib.sed_ms_iterate_workspace_bytes(64, 10000, 128, _lib.MsOptions(0, 3)) == 0
+    # the kernel a call runs is reported by the library itself (bench.py's roofline.kernel), not composed by the caller
+    assert _lib.lib.sed_ms_iterate_kernel_name(64, 10000, 128, None) == b"ms_iterate_f16w_kernel<4, false, true>"
+    assert _lib.lib.sed_ms_iterate_kernel_name(1, 10000, 160, _lib.MsOptions(0, 1)) == b"ms_iterate_f16w_kernel<5, true, false>"
+    assert _lib.lib.sed_ms_iterate_bounds_f16_kernel_name(128, 0) == b"ms_sparse_f16_kernel<true, 4>"
+    assert _lib.lib.sed_ms_iterate_bounds_f16_kernel_name(96, 2) == b""
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -167,32 +167,6 @@ def test_iteration_variants_agree_at_full_size(T):
     np.testing.assert_allclose(one["batched"][0][rows], ref, atol=3e-5)
 
 
-def test_wide_wave_kernel_is_bit_identical(T):
-    """The dense split-fp16 kernel exists with 32 queries per wave (8-wave workgroups, two waves per SIMD) and with 64 (4-wave
-    workgroups, one wave per SIMD and its whole 512-register file; the default): same MFMA order per accumulator, same key order,
-    same row update -- the same bits, in the one-launch and the key-chunked form, with one and with two weight digits, on a
-    ragged last stage, including a cloud whose cancelling means send it through the two-digit redo pass."""
-    from sednet_hip import ops, synth
-    Xs = np.stack([synth.clustered_embedding(N=4999, d=128, n_clusters=9 + c, sigma=0.02, seed=140 + c)[0] for c in range(2)])
-    rnd = T.nn.functional.normalize(T.randn(1, 4999, 128, generator=T.Generator().manual_seed(9)), dim=2)
-    X = T.cat([T.from_numpy(Xs), rnd]).cuda().contiguous()
-    bw = ops.ms_bandwidth(X, 75, 0.003)
-    try:
-        for v in ("f16/1", "f16", "f16c/1", "f16c"):
-            for iters in (1, 7):
-                set_schedule(v)
-                ops.MS_WAVE_QUERIES = 32
-                a = ops.ms_iterate(X, bw, iters)
-                ops.MS_WAVE_QUERIES = 64
-                b = ops.ms_iterate(X, bw, iters)
-                assert T.equal(a, b), (v, iters)
-                ops.MS_WAVE_QUERIES = 0
-                assert T.equal(ops.ms_iterate(X, bw, iters), b)         # the default is the 64-query form
-    finally:
-        ops.MS_WAVE_QUERIES = 0
-        reset_schedule()
-
-
 def test_cancelling_weighted_means_are_redone_with_two_weight_digits(T):
     """The default kernels feed the weights into the second product as fp16 heads; normalising a weighted mean of norm |o|
     amplifies that rounding by 1 / |o|. Unstructured rows under a bandwidth that spans the cloud have |o| ~ 1 / sqrt(N): the
@@ -444,12 +418,12 @@ def test_every_schedule_is_bit_reproducible(T):
         assert all(T.equal(a, b) for a, b in zip(o0, ops.ms_pivot_order(X)))
 
 
-def test_every_form_of_the_block_sparse_kernel(T):
-    """sed_ms_iterate_bounds_f16_f32's `form` argument: 1 (8 waves, four-plane images), 4 (8 waves, row-major images), 5 (4 waves,
-    row-major: the default), 2 / 3 (64 queries per wave, 2- / 4-wave workgroups). All skip by the same rule: rows within the dense
-    kernel's tolerance for every form, with one and with two weight digits; what a WAVE computes does not depend on the workgroup
-    it sits in, so forms 4 and 5 return the same bits; the counters are consistent (second products <= first products <= listed
-    stages x waves; the dense count is the same for every form); ragged N and a flagged (non-unit) cloud in the batch."""
+def test_both_item_orders_of_the_block_sparse_kernel(T):
+    """sed_ms_iterate_bounds_f16_f32's `form` argument only decides in which order a cloud's work items are queued (0: longest
+    first, 1: row order). Rows within the dense kernel's tolerance with one and with two weight digits; what an item computes does
+    not depend on the queue it came from, so both forms return the same bits and the same counts; the counters are consistent
+    (second products <= first products <= the dense count); ragged N and a flagged (non-unit) cloud in the batch; a cloud's rows do
+    not depend on what else is in the call."""
     from sednet_hip import ops, synth
     Xs = np.stack([synth.clustered_embedding(N=4999, d=128, n_clusters=9 + 2 * c, sigma=0.015, seed=300 + c)[0] for c in range(3)])
     Xs[2] *= np.float32(1.2)                                   # flagged by the split kernel: the exact fp32 kernel takes it
@@ -466,7 +440,7 @@ def test_every_form_of_the_block_sparse_kernel(T):
     try:
         for digits in (2, 1):
             ops.ms_set_weight_digits(digits)
-            for form in (1, 2, 3, 4, 5):
+            for form in (0, 1):
                 ops.MS_SPARSE_FORM = form
                 st = T.zeros(5, dtype=T.int64, device="cuda")
                 got = ops.ms_iterate_sparse(X, bw, 12, stats=st)
@@ -475,11 +449,16 @@ def test_every_form_of_the_block_sparse_kernel(T):
                 np.testing.assert_allclose(got[2].cpu().numpy(), exact[2].cpu().numpy(), atol=2e-5)
                 assert T.equal(got, ops.ms_iterate_sparse(X, bw, 12)), form              # same bits run after run
                 rows[digits, form], counts[digits, form] = got, st.cpu().numpy()
-            assert T.equal(rows[digits, 4], rows[digits, 5])
-            for form in (1, 2, 3, 4, 5):
                 c = counts[digits, form]
-                assert c[3] == counts[digits, 1][3] and 0 < c[2] <= c[1] <= c[3] and c[4] > 0, (form, c)
-            assert (counts[digits, 4][1:3] == counts[digits, 5][1:3]).all() and counts[digits, 5][0] > 0
+                assert 0 < c[2] <= c[1] <= c[3] and c[0] > 0 and c[4] > 0, (form, c)
+            assert T.equal(rows[digits, 0], rows[digits, 1])
+            assert (counts[digits, 0] == counts[digits, 1]).all()
+            ops.MS_SPARSE_FORM = 0
+            alone = ops.ms_iterate_sparse(X[1:2].contiguous(), bw[1:2].contiguous(), 12)
+            assert T.equal(alone[0], rows[digits, 0][1])
+        ops.MS_SPARSE_FORM = 2
+        with pytest.raises(RuntimeError):
+            ops.ms_iterate_sparse(X, bw, 2)
     finally:
         ops.MS_SPARSE_FORM = 0
         ops.ms_set_weight_digits(2)
@@ -488,7 +467,7 @@ def test_every_form_of_the_block_sparse_kernel(T):
 def test_block_sparse_kernel_at_the_hpnet_width(T):
     """d = 160 (the HPNet flow's 140 columns, padded): preparation kernels and the block-sparse kernel instantiated for five feature
     tiles -- rows within the dense d = 160 kernel's tolerance, zero pad columns stay zero, blocks are skipped on clustered rows, a
-    non-unit cloud falls back to the exact fp32 kernel of that width, non-default forms are refused."""
+    non-unit cloud falls back to the exact fp32 kernel of that width, both item orders give the same bits."""
     from sednet_hip import ops, synth
     from sednet_hip._lib import lib, ptr, stream
     Xs = np.stack([synth.clustered_embedding(N=4000, d=140, n_clusters=8 + c, sigma=0.006, seed=800 + c)[0] for c in range(3)])
@@ -516,9 +495,8 @@ def test_block_sparse_kernel_at_the_hpnet_width(T):
     assert (T.sort(order, 1)[0] == T.arange(4000, device="cuda")[None]).all()
     assert T.equal(prep["Xs"], T.gather(X, 1, order.unsqueeze(-1).expand(-1, -1, 160)))
     try:
-        ops.MS_SPARSE_FORM = 4
-        with pytest.raises(RuntimeError):
-            ops.ms_iterate_sparse(X, bw, 2)
+        ops.MS_SPARSE_FORM = 1
+        assert T.equal(got, ops.ms_iterate_sparse(X, bw, 10))
     finally:
         ops.MS_SPARSE_FORM = 0
 

@@ -1,0 +1,105 @@
+"""GPU: the device-side branches of sednet_hip.shard on RCCL itself. No multi-GPU node is available to the
+builder, and the gloo tests (tests/test_distributed_cpu.py) stage every collective through host copies -- so before this test
+`host_staged = False` had never executed. A world of ONE rank initialises the `nccl` backend (= RCCL on ROCm) and runs every
+collective shard.py issues on device tensors: all_gather_into_tensor (gather_results), all_gather with padding (gather_ragged),
+the all_reduce / all_gather_into_tensor protocol of balanced_guard_retries, and the flat gradient all_reduce. With one rank every
+collective is the identity, so the results are checked exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dist1():
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_shard_collectives_run_on_rccl(dist1):
+    import torch
+    from sednet_hip import shard
+    dist = dist1
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    B, N = 3, 500
+    out = {"labels": torch.randint(0, 9, (B, N), generator=g, dtype=torch.int32).to(dev),
+           "types": torch.randint(0, 6, (B, N), generator=g, dtype=torch.int32).to(dev),
+           "params": torch.randn(B, 50, 8, generator=g).to(dev),
+           "valid": (torch.rand(B, 50, generator=g) > 0.5).to(dev),
+           "seg_type": torch.randint(0, 6, (B, 50), generator=g, dtype=torch.int32).to(dev),
+           "passes": np.ones(B, np.int64)}
+    res = shard.gather_results(out, dist)
+    for k in shard.GATHER_KEYS:
+        assert res[k].is_cuda and torch.equal(res[k], out[k]), k
+    assert res["passes"] is out["passes"]                       # non-gathered entries pass through
+
+    t = torch.randn(5, 7, generator=g).to(dev)
+    r = shard.gather_ragged(t, dist)
+    assert r.is_cuda and torch.equal(r, t)
+    assert shard.gather_ragged(t[:0], dist).shape == (0, 7)
+
+    # guard-retry balancing: two flagged clouds, processed "remotely" by the only rank; slots travel through device all_reduces
+    X = torch.nn.functional.normalize(torch.randn(2, 64, 128, generator=g), dim=2).to(dev)
+    seen = {}
+
+    def run_fn(Xg, q):
+        seen["X"], seen["q"] = Xg, np.asarray(q)
+        lab = (Xg[:, :, 0] > 0).int() + 1
+        return lab, torch.tensor([0.25, 0.5], device=dev), torch.tensor([2, 2])
+    lab, bw, nl = shard.balanced_guard_retries(X, [0.018, 0.0216], run_fn, dist)
+    assert torch.equal(seen["X"], X) and np.allclose(seen["q"], [0.018, 0.0216])
+    assert lab.is_cuda and torch.equal(lab, (X[:, :, 0] > 0).int() + 1)
+    assert torch.equal(bw.cpu(), torch.tensor([0.25, 0.5])) and nl.tolist() == [2, 2]
+    assert shard.balanced_guard_retries.last_processed == 2
+    lab0, bw0, nl0 = shard.balanced_guard_retries(X[:0], [], run_fn, dist)          # a rank without flagged clouds still joins
+    assert lab0.shape == (0, 64) and bw0.numel() == 0 and nl0.numel() == 0
+
+    # the training step's flat gradient all-reduce
+    m = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.Linear(4, 2)).to(dev)
+    m(torch.randn(5, 8, generator=g).to(dev)).sum().backward()
+    m[1].bias.grad = None                                        # a parameter without a gradient contributes zeros
+    before = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+    shard.allreduce_gradients(m, dist)
+    for p, b in zip(m.parameters(), before):
+        assert p.grad.is_cuda and torch.equal(p.grad, torch.zeros_like(p) if b is None else b)
+
+
+def test_pipeline_guard_loop_through_rccl(dist1):
+    """The pipeline's own collective path (dist given): the clustering stage of a small batch with one cloud that needs guard
+    retries -- the retry rounds go through balanced_guard_retries on RCCL and return what the local loop returns."""
+    import torch
+    from sednet_hip import synth
+    from src.mean_shift import MeanShift
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    d = 128
+    base = rng.normal(size=(30, d)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    twin = base + 0.08 * rng.normal(size=(30, d)); twin /= np.linalg.norm(twin, axis=1, keepdims=True)
+    C = np.concatenate([base, twin])
+    Xg = C[np.repeat(np.arange(60), 20)] + 0.002 * rng.normal(size=(1200, d))
+    Xg = (Xg / np.linalg.norm(Xg, axis=1, keepdims=True)).astype(np.float32)
+    Xe, _ = synth.clustered_embedding(N=1200, d=128, n_clusters=7, sigma=0.01, seed=5)
+    X = torch.from_numpy(np.stack([Xe, Xg])).to(dev)
+    ms = MeanShift()
+    local = ms.guard_mean_shift_batch(X, 0.008, 50, num_samples=1200)
+    coll = ms.guard_mean_shift_batch(X, 0.008, 50, num_samples=1200, dist=dist1)
+    (lab_l, bw_l, nl_l, passes_l), (lab_c, bw_c, nl_c, passes_c) = local, coll
+    assert int(passes_l[1]) >= 2 and int(passes_l[0]) == 1 and list(passes_c) == list(passes_l) and list(nl_c) == list(nl_l)
+    assert torch.equal(lab_c, lab_l) and torch.equal(bw_c, bw_l)

@@ -37,15 +37,20 @@
 // tools/experiments/ms_iterate_f16_round3.hip): the weight phase issues ~85 instead of ~130 vector instructions per block (packed
 // fp32 fma for the exponent, no clamp -- a weight below e^-75 changes neither the fp32 row sum, which holds the self weight 2^14,
 // nor the (h, l) digits, which are 0 below 2^-39 --, liveness from the packed fp16 heads, the dead-stage test only on blocks that
-// are not live), the late / early wave staggering is gone (it measured +-0), and with F16S_ASM_RING the operand ring is read by
-// inline ds_read instructions with hand-counted lgkmcnt waits and the per-stage barrier waits only for the stage copy it needs
-// (vmcnt(one entry) instead of vmcnt(0): the compiler puts s_waitcnt vmcnt(0) in front of every transpose read while LDS-DMA
-// copies are in flight, which ties the prefetch distance to one stage whatever the number of buffers).
+// are not live), the late / early wave staggering is gone (it measured +-0), and with F16S_ASM_DMA the stage copies are issued as
+// inline global_load_lds instructions and the per-stage barrier waits only for the stage copy it needs (vmcnt(one entry) instead
+// of vmcnt(0)): as long as the compiler knows of LDS-DMA copies in flight it puts s_waitcnt vmcnt(0) in front of every transpose
+// read, which ties the prefetch distance to one stage whatever the number of buffers. (Reading the operand ring itself through
+// inline ds_read instructions with hand-counted lgkmcnt waits does NOT work: the register allocator copies ring slots between the
+// load and the wait -- it cannot know the load is still in flight -- and the copies carry stale data: NaN rows, measured.)
 #include "ms_f16_common.h"
 #include <type_traits>
 
-#ifndef F16S_ASM_RING
-#define F16S_ASM_RING 1
+#ifndef F16S_ASM_DMA
+#define F16S_ASM_DMA 1
+#endif
+#ifndef F16S_WAIT_ALL
+#define F16S_WAIT_ALL 0          // 1: the stage barrier waits for every copy in flight (A/B of the prefetch distance)
 #endif
 #ifndef F16S_DELTA_V
 #define F16S_DELTA_V 0.005f
@@ -88,33 +93,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// LDS instructions of operand-ring step u (mod 4 NT): 2 (first-product operands: one ds_read_b128 per plane) or 4 (transpose reads)
-template <int NT>
-__host__ __device__ constexpr int f16s_ring_ops(int u) { return (u % (4 * NT)) < 2 * NT ? 2 : 4; }
-
 typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
-
-#if F16S_ASM_RING
-// LDS reads the compiler's waitcnt pass does not see (it would wait for every LDS-DMA copy in flight before them); the consumer
-// waits through ring_wait<N>: N = LDS instructions issued after the ones whose result is wanted (LDS returns in order).
-template <int OFF>
-__device__ __forceinline__ h16x8 lds_read_b128(unsigned addr) {
-    h16x8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ v4s lds_read_tr16_b64(unsigned addr) {
-    v4s v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void ring_wait(h16x8& a, h16x8& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-#endif
 
 template <bool PL, int NT>     // PL = false: fp16 heads of the weights only (weight_digits = 1, see ms_iterate_f16.hip)
 __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
@@ -209,15 +189,27 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
     }
 
     const unsigned lane16 = lane * 16;
+    // One 1 KiB piece of an LDS-DMA copy: 16 B per lane from g (per lane) to l + 16 lane (l wave-uniform).
+    // F16S_ASM_DMA: issued as inline instructions -- the compiler then does not know that LDS-DMA copies are in flight in the stage
+    // loop; knowing it, it puts s_waitcnt vmcnt(0) in front of every transpose read, which ties the prefetch distance to ONE stage
+    // whatever the number of buffers. Completion is waited for explicitly (stage barrier / vmcnt(0) before the reference planes are
+    // read). Every copy of this kernel goes through here, so the compiler itself never programs m0.
+    auto dma_piece = [&](const uint8_t* g, uint8_t* l) {
+#if F16S_ASM_DMA
+        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)l;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
+#else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                         16, 0, 0);
+#endif
+    };
     auto stage_dma = [&](int st, int buf) {              // 17 / 21 pieces of 1 KiB dealt round-robin to the waves
         const uint8_t* src = blob_c + (size_t)st * STAGE;
         uint8_t* dst = lds + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
             const int pc = wave + NW * i;
-            if (pc < NPIECE)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 1024 + lane16),
-                                                 (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+            if (pc < NPIECE) dma_piece(src + pc * 1024 + lane16, dst + pc * 1024);
         }
     };
 
@@ -229,26 +221,6 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
     const int xoff_nat = li * XROW + hi * 16;             // natural row order (reference planes)
     const int xoff = (16 * (li >> 4) + 4 * (li & 3) + ((li >> 2) & 3)) * XROW + hi * 16;
     const int toff = (4 * ((lane & 15) >> 2) + hi) * XROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-#if F16S_ASM_RING
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)lds;
-    auto ring_load = [&](auto tc, int buf) {
-        constexpr int t = decltype(tc)::value;
-        if constexpr (t < KS) {
-            const unsigned a = lds0 + (unsigned)(buf * STAGE + xoff);
-            fa[t & 3] = lds_read_b128<t * 32>(a);
-            fb[t & 3] = lds_read_b128<OFF_XL + t * 32>(a);
-        } else {
-            constexpr int c = (t - KS) >> 1, j = (t - KS) & 1;
-            const unsigned a = lds0 + (unsigned)(buf * STAGE + toff);
-            const v4s h0 = lds_read_tr16_b64<(16 * j) * XROW + 64 * c>(a);
-            const v4s h1 = lds_read_tr16_b64<(16 * j + 2) * XROW + 64 * c>(a);
-            const v4s l0 = lds_read_tr16_b64<OFF_XL + (16 * j) * XROW + 64 * c>(a);
-            const v4s l1 = lds_read_tr16_b64<OFF_XL + (16 * j + 2) * XROW + 64 * c>(a);
-            fa[t & 3] = __builtin_bit_cast(h16x8, (v8s)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-            fb[t & 3] = __builtin_bit_cast(h16x8, (v8s)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-    };
-#else
     auto tr8 = [&](const uint8_t* plane, int c, int j) {
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) v4s*)(plane + toff + (16 * j) * XROW + 64 * c));
@@ -268,12 +240,11 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
             fb[t & 3] = tr8(base + OFF_XL, c, j);
         }
     };
-#endif
     // the stage barrier: every wave's share of the NEXT entry's copy has landed (the newest entry -- issued NBUF - 1 entries ahead
     // -- may still be in flight where a newer one exists), LDS writes are visible
     auto stage_barrier = [&](bool newest_is_needed) {
-#if F16S_ASM_RING
-        if (NBUF < 4 || newest_is_needed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if F16S_ASM_DMA
+        if (NBUF < 4 || newest_is_needed || F16S_WAIT_ALL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,9 +291,7 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
             if (g0 > 0) __syncthreads();                      // every wave is done with the previous group's planes
             for (int pc = wave; pc < ng * REFP; pc += NW) {   // 1 KiB pieces: image pc / REFP, piece pc % REFP
                 const int im = pc / REFP, piece = pc - REFP * im;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16),
-                    (__attribute__((address_space(3))) void*)(lds + im * REFB + piece * 1024), 16, 0, 0);
+                dma_piece(ref_c + (size_t)(g0 + im) * STAGE + piece * 1024 + lane16, lds + im * REFB + piece * 1024);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -415,9 +384,6 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 static_for<0, KS>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-#if F16S_ASM_RING
-                    ring_wait<f16s_ring_ops<NT>(t + 1) + f16s_ring_ops<NT>(t + 2)>(fa[t & 3], fb[t & 3]);
-#endif
                     s = mfma16(fb[t & 3], qh[t], s);
                     s = mfma16(fa[t & 3], ql[t], s);
                     s = mfma16(fa[t & 3], qh[t], s);
@@ -484,13 +450,6 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                 static_for<KS, NSTEP>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
                     constexpr int c = (t - KS) >> 1, jj = (t - KS) & 1;
-#if F16S_ASM_RING
-                    // steps t + 1, t + 2 past the end of the block load the next stage's first operands only when there is one
-                    constexpr int in_block = (t + 1 < NSTEP ? f16s_ring_ops<NT>(t + 1) : 0) + (t + 2 < NSTEP ? f16s_ring_ops<NT>(t + 2) : 0);
-                    constexpr int beyond = (t + 1 >= NSTEP ? 2 : 0) + (t + 2 >= NSTEP ? 2 : 0);
-                    if (beyond == 0 || !more) ring_wait<in_block>(fa[t & 3], fb[t & 3]);
-                    else ring_wait<in_block + beyond>(fa[t & 3], fb[t & 3]);
-#endif
                     o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
                     if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
                     o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
@@ -499,17 +458,10 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else if (more) {
-#if F16S_ASM_RING
-                // (the ring may hold transpose reads in flight whose slots the loads below reuse: drain first)
-                if (need) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
                 static_for<0, 3>([&](auto tc) { ring_load(tc, nbuf); });
             }
             buf = nbuf;
         }
-#if F16S_ASM_RING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of the ring is in flight past the sweep
-#endif
 
         // ---- row update (mean_shift.py:70-77)
         const float rs = rsum + xor32(rsum);

@@ -52,6 +52,9 @@
 #ifndef F16S_WAIT_ALL
 #define F16S_WAIT_ALL 0          // 1: the stage barrier waits for every copy in flight (A/B of the prefetch distance)
 #endif
+#ifndef F16S_PROFILE
+#define F16S_PROFILE 0           // 1: stats[5 .. 9] += per-wave clock ticks (s_memtime) spent in the stage barrier / in the whole sweep /
+#endif                           //    in first product + weights / in the second product / blocks timed (tools/sparse_ab.py prints them)
 #ifndef F16S_DELTA_V
 #define F16S_DELTA_V 0.005f
 #endif
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
     const int nst = (N + 31) >> 5;
     const int nrs = 2 * ((nst + 31) >> 5);               // reference images: image 2 k + w = w-th references of tiles 32 k ..
     unsigned n_listed = 0, n_first = 0, n_second = 0, n_remake = 0, n_dense = 0;      // wave-uniform counts (statistics only)
+#if F16S_PROFILE
+    unsigned long long t_bar = 0, t_sweep = 0, t_fp = 0, t_sp = 0;
+#define F16S_NOW() __builtin_readcyclecounter()
+#endif
     for (;;) {
     __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
     if (tid == 0) item_sh = ms_next_item(sched, item_list, head0, nitems, nbx);
@@ -369,6 +376,9 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         __syncthreads();
         if (ns > 0) static_for<0, 3>([&](auto tc) { ring_load(tc, 0); });
         int buf = 0;
+#if F16S_PROFILE
+        const unsigned long long t_s0 = F16S_NOW();
+#endif
         for (int j = 0; j < ns; ++j) {
             const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
             const int st = entry(j);
@@ -377,6 +387,9 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
             const bool need =
                 __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
             bool live = false;
+#if F16S_PROFILE
+            const unsigned long long t_a = F16S_NOW();
+#endif
             if (need) {
                 // ---- first product S^T = X_tile Q^T (keys on accumulator rows) ...
                 f32x16 s;
@@ -441,7 +454,16 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                 ++n_first;
             }
             // B_j: every wave is past entry j - 1 (its buffer is free) and has entry j + 1's copy in LDS
+#if F16S_PROFILE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t_b = F16S_NOW();
             stage_barrier(j + NBUF - 1 > ns);
+            const unsigned long long t_c = F16S_NOW();
+            t_fp += t_b - t_a;
+            t_bar += t_c - t_b;
+#else
+            stage_barrier(j + NBUF - 1 > ns);
+#endif
             // entry j + NBUF - 1 goes into the buffer entry j - 1 has left
             if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
 
@@ -461,7 +483,13 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                 static_for<0, 3>([&](auto tc) { ring_load(tc, nbuf); });
             }
             buf = nbuf;
+#if F16S_PROFILE
+            t_sp += F16S_NOW() - t_c;
+#endif
         }
+#if F16S_PROFILE
+        t_sweep += F16S_NOW() - t_s0;
+#endif
 
         // ---- row update (mean_shift.py:70-77)
         const float rs = rsum + xor32(rsum);
@@ -548,6 +576,12 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         atomicAdd(stats + 2, (unsigned long long)n_second);
         atomicAdd(stats + 3, (unsigned long long)n_dense);
         if (wave == 0) atomicAdd(stats + 4, (unsigned long long)n_remake);
+#if F16S_PROFILE
+        atomicAdd(stats + 5, t_bar);
+        atomicAdd(stats + 6, t_sweep);
+        atomicAdd(stats + 7, t_fp);
+        atomicAdd(stats + 8, t_sp);
+#endif
     }
 }
 
@@ -627,7 +661,7 @@ const char* ms_f16_sparse_kernel_name(int d, int digits) {
 template <int NT>
 static int f16s_launch(int B, int N, int iters, const float* bw, const float* X, float* newX, uint8_t* blob, int* flags,
                        uint8_t* refblob, int* flags2, int* lowq, float skip_below, const float* tile_ref, const float* tile_cosalpha,
-                       float margin, unsigned long long* stats, int digits, int row_order, int* sched, hipStream_t stream) {
+                       float margin, unsigned long long* stats, int digits, int row_order, int one_per_cu, int* sched, hipStream_t stream) {
     constexpr int NW = F16S_NW;
     const int nst = (N + 31) / 32, nrs = 2 * ((nst + 31) / 32);
     constexpr int sm = (NT == 4 ? 4 : 3) * StageLayoutD<NT>::STAGE;
@@ -646,7 +680,7 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
     e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
-    slots *= 8 / NW;
+    if (!one_per_cu) slots *= 8 / NW;                      // (one workgroup per CU: measurement only -- form bit 1)
     const dim3 grid((unsigned)(nitems < slots ? nitems : slots));
     int* item_stages = sched + MS_SCHED_INTS;              // [MS_SCHED_INTS] queues (ms_next_item) | [nitems] first list lengths | [nitems] item list
     int* item_list = item_stages + nitems;
@@ -684,7 +718,8 @@ static int f16s_launch(int B, int N, int iters, const float* bw, const float* X,
 // row (2 (t / 32) + w) 32 + t % 32 = w-th reference of tile t; tile_ref [B, nref, d] unit vectors (unused rows zero),
 // tile_cosalpha [B, nref] = smallest dot product of a row of the reference's group with it.
 // workspace = ms_f16_sparse_workspace_bytes(B, N, d); stats (optional, device, 5 x u64, accumulated; the redo pass is not counted).
-// form: 0 = default; bit 0 set = a cloud's items are queued in row order instead of longest first.
+// form: 0 = default; bit 0 set = a cloud's items are queued in row order instead of longest first; bit 1 set = ONE resident
+// workgroup per CU instead of two (a measurement switch: how much do the two waves of a SIMD overlap?).
 int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const float* X, float* newX, void* workspace,
                          int** flags_out, float skip_below, const float* tile_ref, const float* tile_cosalpha,
                          float margin, unsigned long long* stats, int digits, int form, hipStream_t stream) {
@@ -702,10 +737,10 @@ int ms_f16_sparse_launch(int B, int N, int d, int iters, const float* bw, const 
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(lowq, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
-    const int row_order = form & 1;
+    const int row_order = form & 1, one_per_cu = (form >> 1) & 1;
     if (d == 160)
         return f16s_launch<5>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
-                              stats, digits, row_order, sched, stream);
+                              stats, digits, row_order, one_per_cu, sched, stream);
     return f16s_launch<4>(B, N, iters, bw, X, newX, blob, flags, refblob, flags2, lowq, skip_below, tile_ref, tile_cosalpha, margin,
-                          stats, digits, row_order, sched, stream);
+                          stats, digits, row_order, one_per_cu, sched, stream);
 }

@@ -456,7 +456,7 @@ def test_both_item_orders_of_the_block_sparse_kernel(T):
             ops.MS_SPARSE_FORM = 0
             alone = ops.ms_iterate_sparse(X[1:2].contiguous(), bw[1:2].contiguous(), 12)
             assert T.equal(alone[0], rows[digits, 0][1])
-        ops.MS_SPARSE_FORM = 2
+        ops.MS_SPARSE_FORM = 4
         with pytest.raises(RuntimeError):
             ops.ms_iterate_sparse(X, bw, 2)
     finally:
@@ -743,7 +743,7 @@ def test_hpnet_width_runs_the_split_fp16_kernels(T):
         assert T.equal(ops.ms_bandwidth(X, 90, 0.003), bw)                   # materialised path: the same bits
     finally:
         ops.KTH_FUSED_MIN_BLOCKS = 0
-    assert lib.sed_ms_iterate_plan(3, N, 160, MsOptions(0, 0, 0)) == 5 and lib.sed_ms_iterate_plan(64, N, 160, MsOptions(0, 0, 0)) == 4
+    assert lib.sed_ms_iterate_plan(3, N, 160, MsOptions(0, 0)) == 5 and lib.sed_ms_iterate_plan(64, N, 160, MsOptions(0, 0)) == 4
     res = {}
     try:
         for v in ("batched", "f16", "f16/1", "f16c", "f16c/1"):

@@ -63,13 +63,17 @@ prep_ts, prep = timed(lambda: ops.ms_sparse_prepare(X))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 for form in forms:
     ops.MS_SPARSE_FORM = form
-    stats = torch.zeros(5, dtype=torch.int64, device=dev)
+    stats = torch.zeros(16, dtype=torch.int64, device=dev)
     ts, out = timed(lambda: ops.ms_sparse_run(prep, bw, 50, ops.MS_SPARSE_SKIP, stats=stats))
     cnt = stats.cpu().numpy().astype(float)
     err = (out - dense).abs()
     line = (f"{tag} form {form} d={X.shape[2]}: sparse call min {min(ts):.1f} median {float(np.median(ts)):.1f} ms (prep {min(prep_ts):.2f}); "
             f"first {cnt[1] / cnt[3]:.4f} second {cnt[2] / cnt[3]:.4f} of dense; listed {cnt[0]:.3e}; "
             f"vs dense: max {err.max().item():.2e}, median of cloud maxima {err.amax((1, 2)).median().item():.2e}")
+    if cnt[6] > 0:          # a -DF16S_PROFILE=1 build: per-wave clock ticks (4 timed calls)
+        line += (f"; PROFILE per wave: stage barrier {cnt[5] / cnt[6]:.3f} of the sweep time, first product + weights {cnt[7] / cnt[6]:.3f}, "
+                 f"second product (+ copies issue) {cnt[8] / cnt[6]:.3f}; ticks per first product {cnt[7] / cnt[1]:.0f}, per second product "
+                 f"{cnt[8] / cnt[2]:.0f}, barrier ticks per listed stage and wave {cnt[5] / (4 * cnt[0]):.0f}, sweep ticks per wave-block {cnt[6] / cnt[1]:.0f}")
     key = f"/tmp/sparse_ab_rows_{'d160' if d160 else 'd128'}_"
     for other in sorted(f for f in os.listdir("/tmp") if f.startswith(os.path.basename(key))):
         prev = torch.load(os.path.join("/tmp", other)).to(dev)

@@ -17,7 +17,8 @@ Quirks kept on purpose:
   * knn_idx takes topk *largest* squared distances: the "50 neighbours" are the 50 FARTHEST points (:35-39);
   * the affinity matrix is dense with 1e-12 background, so the mask in the symmetrisation is all ones (:73-90);
   * compute_entropy covers only the first ITER * CHUNK = 5 * CHUNK points but divides by N^2 (:105, :119-152);
-  * torch.lobpcg starts from a random block: results are reproducible only under a fixed torch seed.
+  * torch.lobpcg starts from a random block: results are reproducible only under a fixed torch seed (here: the start of a cloud
+    is a function of torch.initial_seed() and the cloud, see lobpcg_start).
 The reference's disk cache of eigenvectors (src/normal_smooth_cache/*.pt, :189-202) is not reproduced (pass `cache_dir`
 to enable an equivalent).
 """
@@ -100,10 +101,44 @@ def affinity_apply(op, X, out=None):
     return Y
 
 
+_M64 = (1 << 64) - 1
+
+
+def _i64(v):
+    """python int -> the same 64 bits as a signed int64 constant"""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def keyed_randn(keys, n):
+    """Standard-normal numbers [B, n] as a pure function of one int64 key per cloud (device tensor) -- counter-based (two rounds of
+    the splitmix64 finaliser over key + counter, Box-Muller), evaluated with torch integer ops on the device: no generator state,
+    no host round trip. The LOBPCG start of a cloud is then a function of (torch.initial_seed(), the cloud itself), not of the
+    cloud's position in the batch or of what else was drawn from torch's global generator before."""
+    dev = keys.device
+    ctr = torch.arange(2 * n, device=dev, dtype=torch.int64).view(1, 2 * n)
+    z = keys.view(-1, 1) + ctr * _i64(0x9E3779B97F4A7C15)
+    for mul, sh in ((0xBF58476D1CE4E5B9, 30), (0x94D049BB133111EB, 27)):
+        z = (z ^ ((z >> sh) & ((1 << (64 - sh)) - 1))) * _i64(mul)
+    z = z ^ ((z >> 31) & ((1 << 33) - 1))
+    u = (((z >> 11) & ((1 << 53) - 1)).double() + 0.5) * (1.0 / (1 << 53))         # (0, 1)
+    u1, u2 = u[:, :n], u[:, n:]
+    return (torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)).float()
+
+
+def lobpcg_start(d, k):
+    """the random start block [B,N,k] of lobpcg_sparse: keyed by torch.initial_seed() and a digest of the cloud's own operator"""
+    B, N = d.shape
+    digest = (d.double().sum(1) * float(1 << 40)).long() ^ (d[:, ::97].double().sum(1) * float(1 << 44)).long()
+    keys = digest * _i64(0xD1342543DE82EF95) + _i64(torch.initial_seed() * 0x2545F4914F6CDD1D)
+    return keyed_randn(keys, N * k).view(B, N, k)
+
+
 def lobpcg_sparse(op, k=12, niter=10, X0=None):
     """k largest eigenpairs of A_sym by LOBPCG (Knyazev 2001: block [X, R, P], no preconditioner), all clouds of the
     batch at once; the counterpart of torch.lobpcg(A, k=12, niter=10) at smooth_normal_matrix.py:198. Random normal
-    start from torch's global generator on the device (seed with torch.manual_seed for reproducibility).
+    start per cloud from lobpcg_start: a function of torch.initial_seed() (torch.manual_seed for another draw) and of the cloud
+    itself, so a cloud's eigenvectors -- and its labels -- do not depend on the batch it is in.
     Round 3: everything inside the iteration runs in HIP kernels on the device (lobpcg.hip: tall-skinny Gram products with fp64
     accumulation, the 36 x 36 Rayleigh-Ritz problems by cyclic Jacobi in fp64, the block updates) -- no library GEMM, no LAPACK,
     no D->H copy between the first launch and the result. The search block lives in two buffers S, AS [B,N,36] = [X | R | P].
@@ -115,7 +150,7 @@ def lobpcg_sparse(op, k=12, niter=10, X0=None):
     B, N = d.shape
     S = torch.zeros(B, N, 3 * k, dtype=torch.float32, device=d.device)
     AS = torch.zeros_like(S)
-    S[:, :, :k] = torch.randn(B, N, k, device=d.device) if X0 is None else X0
+    S[:, :, :k] = lobpcg_start(d, k) if X0 is None else X0
     X, AX, R, AR = S[:, :, :k], AS[:, :, :k], S[:, :, k:2 * k], AS[:, :, k:2 * k]
     affinity_apply(op, X, out=AX)
     C, lam = ops.ritz(ops.tsgemm_tn(X, X), ops.tsgemm_tn(X, AX), k)      # also orthonormalises the random block

@@ -113,3 +113,60 @@ def test_sparse_lobpcg_finds_the_leading_eigenvectors(T, golden):
     assert int((sv > 0.75).sum()) >= 6, sv
     lam60, V60 = snm.lobpcg_sparse(op, k=12, niter=60)
     np.testing.assert_allclose(lam60[0, :6].cpu().numpy(), w[:6].cpu().numpy(), rtol=2e-3)
+
+
+def test_default_flow_at_contract_size_inside_the_references_own_spread(T, golden, capsys):
+    """The reference script's DEFAULT flow (HPNet_embed = True, generate_predictions_aug.py:58, :371-384) at N = 10 000 against the
+    reference itself. torch.lobpcg starts from a random block, so the reference's labels differ between its OWN
+    runs: tests/golden/f_hpnet10k.npz holds bench clouds 0 and 1 through the reference's dense route for four torch seeds each
+    (make_hpnet10k.py: pairwise label agreement of its runs 0.998-0.999 on cloud 0, 0.92-0.99 on cloud 1; 8 and 5-6 clusters; seg-IoU
+    0.4585-0.4591 and 0.41-0.55). The device flow (sparse operator, device LOBPCG, d = 160 mean-shift) for four seeds: its agreement
+    with the reference's runs must be inside the spread of the reference's runs among themselves, cluster counts, bandwidths and
+    seg-IoU inside the reference's ranges. And the flow is a function of the cloud: cloud 1 alone gives the labels it gets in the
+    batch."""
+    import torch
+    from conftest import label_agreement
+    from sednet_hip import synth
+    from sednet_hip.pipeline import SegmentationPipeline
+    from src.segment_utils import seg_iou
+    from test_gpu_baseline_configs import build
+    g = golden("f_hpnet10k")
+    x, gt, _ = synth.batch_clouds(2, 10000, seed0=1234)
+    pipe = SegmentationPipeline(build(T, 20, "type"), build(T, 20, "inst"), quantile=0.015, iterations=50, hpnet=True)
+    xb = torch.from_numpy(x).cuda()
+    dev_labels, dev_bw = [], []
+    for s in (21, 22, 23, 24):
+        torch.manual_seed(s)
+        out = pipe(xb)
+        dev_labels.append(out["labels"].cpu().numpy())
+        dev_bw.append(out["bw"].cpu().numpy())
+    torch.manual_seed(24)
+    alone = pipe(xb[1:2])["labels"][0].cpu().numpy()
+    np.testing.assert_array_equal(alone, dev_labels[-1][1])                     # same seed, alone or in the batch: the same labels
+    rep = []
+    for c in (0, 1):
+        tag = f"c{c}_"
+        assert abs(x[c].astype(np.float64).sum() - float(g[tag + "x_sum"])) < 1e-3
+        ref = g[tag + "labels"]
+        rr = [label_agreement(ref[i], ref[j])["rate"] for i in range(4) for j in range(i + 1, 4)]
+        dr = [label_agreement(dev_labels[i][c], ref[j])["rate"] for i in range(4) for j in range(4)]
+        dd = [label_agreement(dev_labels[i][c], dev_labels[j][c])["rate"] for i in range(4) for j in range(i + 1, 4)]
+        ncl = [int(np.unique(dev_labels[i][c]).size) for i in range(4)]
+        iou = [seg_iou(dev_labels[i][c], gt[c]) for i in range(4)]
+        bws = [float(dev_bw[i][c]) for i in range(4)]
+        rep.append(f"cloud {c}: label agreement reference-reference {min(rr):.3f} .. {max(rr):.3f} (median {np.median(rr):.3f}), "
+                   f"device-reference {min(dr):.3f} .. {max(dr):.3f} (median {np.median(dr):.3f}), device-device {min(dd):.3f} .. {max(dd):.3f}; "
+                   f"clusters reference {g[tag + 'clusters'].tolist()} device {ncl}; bandwidth reference {np.round(g[tag + 'bw'], 4).tolist()} "
+                   f"device {np.round(bws, 4).tolist()}; seg-IoU reference {np.round(g[tag + 'seg_iou'], 4).tolist()} device {np.round(iou, 4).tolist()}")
+        assert min(dr) >= min(rr) - 0.02 and np.median(dr) >= np.median(rr) - 0.02, rep[-1]
+        assert min(ncl) >= int(g[tag + "clusters"].min()) - 1 and max(ncl) <= int(g[tag + "clusters"].max()) + 1, rep[-1]
+        assert min(bws) >= 0.97 * float(g[tag + "bw"].min()) and max(bws) <= 1.03 * float(g[tag + "bw"].max()), rep[-1]
+        assert min(iou) >= float(g[tag + "seg_iou"].min()) - 0.02 and max(iou) <= float(g[tag + "seg_iou"].max()) + 0.02, rep[-1]
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "r04_hpnet_10k_vs_reference.md"), "w") as f:
+        f.write("# The default (HPNet-on) flow at N = 10 000 against the reference's own seed-to-seed spread "
+                "(tests/test_gpu_hpnet.py, tests/golden/f_hpnet10k.npz)\n\n" + "\n".join("* " + r for r in rep) + "\n")
+    with capsys.disabled():
+        print("\n" + "\n".join(rep))

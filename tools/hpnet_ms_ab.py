@@ -1,0 +1,51 @@
+"""Mean-shift on the REAL HPNet-widened embeddings of the bench clouds (140 columns, padded to 160): which schedule should a cloud
+take? Near fractions, the time of the current per-cloud policy, of all clouds block-sparse, of all clouds dense (key-chunked), and
+per near-fraction group block-sparse against dense:   python tools/hpnet_ms_ab.py [B]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sed-net_amd")]
+import numpy as np, torch
+import bench
+from sednet_hip import ops, synth
+from src import smooth_normal_matrix as snm
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = torch.device("cuda")
+x = torch.from_numpy(synth.batch_clouds(B, 10000, seed0=1234)[0]).to(dev)
+m_type, m_inst = bench.build_models(20, dev)
+with torch.no_grad():
+    emb = torch.cat([m_inst.forward_point_major(x[b:b + 16].contiguous(), None)[0] for b in range(0, B, 16)])[:, :, :128].contiguous()
+pts, nrm = x[:, 0:3].transpose(1, 2).contiguous(), x[:, 3:6].transpose(1, 2).contiguous()
+torch.manual_seed(0)
+wide = snm.hpnet_process(emb, pts, nrm, normal_smooth_w=0.5, CHUNK=1000)
+X = ops.row_normalize(wide.contiguous(), wide.shape[2])
+bw = ops.ms_bandwidth(X, 150, 0.003)
+near = ops.ms_near_fraction(X, bw, ops.MS_SPARSE_SKIP).cpu().numpy()
+print("d =", X.shape[2], "bw min/median/max", float(bw.min()), float(bw.median()), float(bw.max()))
+print("near fractions sorted:", np.round(np.sort(near), 2))
+
+
+def t(fn, n=2):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), r
+
+
+ms_, _ = t(lambda: ops.ms_iterate(X, bw, 50))
+print(f"current policy (sparse below {ops.MS_SPARSE_MAX_NEAR}): {ms_:.1f} ms for {B} clouds; {ops.MS_SPARSE_STATS}")
+st = torch.zeros(16, dtype=torch.int64, device=dev)
+ms_s, out_s = t(lambda: ops.ms_iterate_sparse(X, bw, 50, ops.MS_SPARSE_SKIP, stats=st))
+c = st.cpu().numpy().astype(float)
+print(f"all block-sparse: {ms_s:.1f} ms; first {c[1] / c[3]:.3f} second {c[2] / c[3]:.3f} of dense")
+ms_d, out_d = t(lambda: ops._ms_iterate_dense_by_cloud(X, bw, 50))
+print(f"all dense (key-chunked, groups of {ops.MS_DENSE_GROUP}): {ms_d:.1f} ms; rows sparse vs dense max {float((out_s - out_d).abs().max()):.2e}")
+order = np.argsort(near)
+for lo in range(0, B, 8):
+    sel = torch.as_tensor(order[lo:lo + 8], device=dev)
+    Xg, bg = X[sel].contiguous(), bw[sel].contiguous()
+    a, _ = t(lambda: ops.ms_iterate_sparse(Xg, bg, 50, ops.MS_SPARSE_SKIP))
+    b, _ = t(lambda: ops._ms_iterate_dense_by_cloud(Xg, bg, 50))
+    print(f"clouds with near fraction {near[order[lo]]:.2f} .. {near[order[min(lo + 7, B - 1)]]:.2f}: sparse {a / 8:.2f} ms per cloud, dense {b / 8:.2f}")

@@ -34,20 +34,24 @@
 // a cloud's result does not depend on what else is in the launch.
 //
 // Round 4 (this file; the round-3 kernel with its 8-wave / four-plane / list-driven forms is archived in
-// tools/experiments/ms_iterate_f16_round3.hip): the weight phase issues ~85 instead of ~130 vector instructions per block (packed
-// fp32 fma for the exponent, no clamp -- a weight below e^-75 changes neither the fp32 row sum, which holds the self weight 2^14,
-// nor the (h, l) digits, which are 0 below 2^-39 --, liveness from the packed fp16 heads, the dead-stage test only on blocks that
-// are not live), the late / early wave staggering is gone (it measured +-0), and with F16S_ASM_DMA the stage copies are issued as
-// inline global_load_lds instructions and the per-stage barrier waits only for the stage copy it needs (vmcnt(one entry) instead
-// of vmcnt(0)): as long as the compiler knows of LDS-DMA copies in flight it puts s_waitcnt vmcnt(0) in front of every transpose
-// read, which ties the prefetch distance to one stage whatever the number of buffers. (Reading the operand ring itself through
-// inline ds_read instructions with hand-counted lgkmcnt waits does NOT work: the register allocator copies ring slots between the
-// load and the wait -- it cannot know the load is still in flight -- and the copies carry stale data: NaN rows, measured.)
+// tools/experiments/ms_iterate_f16_round3.hip). What changed, all bit-identical to the round-3 rows: the weight phase issues ~85
+// instead of ~130 vector instructions per block (packed fp32 fma for the exponent, no clamp -- a weight below e^-75 changes neither
+// the fp32 row sum, which holds the self weight 2^14, nor the (h, l) digits, which are 0 below 2^-39 --, liveness from the packed
+// fp16 heads, the dead-stage test only on blocks that are not live); the late / early wave staggering is gone; list entries and
+// need bits are read one entry ahead. Measured on the bench embeddings (profiles/r04_sparse_kernel_experiments.md): NONE of it
+// moves the launch (179-180 ms) -- the kernel runs at the package POWER LIMIT (1.3 kW of 1.4 kW, 2.1-2.2 GHz instead of 2.4):
+// time follows the energy of the executed blocks (MFMAs, LDS operand reads, stage copies), not the instruction count or the
+// latency exposure of a wave. Two switches kept for the record, both measured +-0 and off by default:
+//   F16S_ASM_DMA  stage copies issued as inline global_load_lds instructions and a stage barrier that waits only for the copy it
+//                 needs (vmcnt(one entry) instead of vmcnt(0)): while the compiler knows of LDS-DMA copies in flight it puts
+//                 s_waitcnt vmcnt(0) in front of every transpose read, which ties the prefetch distance to one stage.
+//   (not kept: the operand ring read through inline ds_read instructions with hand-counted lgkmcnt waits -- the register
+//    allocator copies ring slots between a load and its wait, it cannot know the load is in flight: NaN rows.)
 #include "ms_f16_common.h"
 #include <type_traits>
 
 #ifndef F16S_ASM_DMA
-#define F16S_ASM_DMA 1
+#define F16S_ASM_DMA 0
 #endif
 #ifndef F16S_WAIT_ALL
 #define F16S_WAIT_ALL 0          // 1: the stage barrier waits for every copy in flight (A/B of the prefetch distance)
@@ -376,16 +380,25 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         __syncthreads();
         if (ns > 0) static_for<0, 3>([&](auto tc) { ring_load(tc, 0); });
         int buf = 0;
+        // List entries and this wave's need bits are read from LDS one entry AHEAD and handed to the scalar unit late: a plain
+        // slist[..] -> wmask[..] chain at the top of every entry costs two exposed LDS round trips per listed stage (and drains the
+        // operand ring each time); the copy's entry (j + NBUF - 1) is fetched the same way.
+        auto slot = [&](int j) { return fwd ? j : ns - 1 - j; };
+        auto need_bit = [&](int st_) { return (int)((wmask[wave][st_ >> 6] >> (st_ & 63)) & 1ull); };
+        int st_cur = ns > 0 ? __builtin_amdgcn_readfirstlane(slist[slot(0)]) : 0;
+        bool need_cur = ns > 0 && __builtin_amdgcn_readfirstlane(need_bit(st_cur)) != 0;
 #if F16S_PROFILE
         const unsigned long long t_s0 = F16S_NOW();
 #endif
         for (int j = 0; j < ns; ++j) {
             const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
-            const int st = entry(j);
+            const int st = st_cur;
             const int key0 = st * 32;
             const bool more = j + 1 < ns;                 // the ring goes on into the next listed stage
-            const bool need =
-                __builtin_amdgcn_readfirstlane((int)((wmask[wave][st >> 6] >> (st & 63)) & 1ull)) != 0;
+            const bool need = need_cur;
+            // issued here, consumed after the barrier / at the end of the entry (the asm barrier's memory clobber keeps them here)
+            const int v_next = more ? slist[slot(j + 1)] : 0;
+            const int v_copy = j + NBUF - 1 < ns ? slist[slot(j + NBUF - 1)] : 0;
             bool live = false;
 #if F16S_PROFILE
             const unsigned long long t_a = F16S_NOW();
@@ -465,7 +478,9 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
             stage_barrier(j + NBUF - 1 > ns);
 #endif
             // entry j + NBUF - 1 goes into the buffer entry j - 1 has left
-            if (j + NBUF - 1 < ns) stage_dma(entry(j + NBUF - 1), buf == 0 ? NBUF - 1 : buf - 1);
+            if (j + NBUF - 1 < ns) stage_dma(__builtin_amdgcn_readfirstlane(v_copy), buf == 0 ? NBUF - 1 : buf - 1);
+            const int st_next = __builtin_amdgcn_readfirstlane(v_next);
+            const unsigned long long w_next = more ? wmask[wave][st_next >> 6] : 0ull;      // this wave's own mask word, used at the end
 
             if (live) {
                 ++n_second;
@@ -483,6 +498,8 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                 static_for<0, 3>([&](auto tc) { ring_load(tc, nbuf); });
             }
             buf = nbuf;
+            st_cur = st_next;
+            need_cur = __builtin_amdgcn_readfirstlane((int)((w_next >> (st_next & 63)) & 1ull)) != 0;
 #if F16S_PROFILE
             t_sp += F16S_NOW() - t_c;
 #endif

@@ -71,6 +71,14 @@ int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int
  * row, deterministic).                                                  src/smooth_normal_matrix.py:42-92, :198 */
 int sed_csr_spmm_f32(int B, int N, int ncol, size_t nnz_stride, const int* rowptr, const int* col, const float* val,
                      const float* X, int ldx, float* Y, int ldy, sed_stream_t stream);
+/* The CSR of that sparse part built on the device: normals [B,N,3] (unit), nn [B,N,knn] = the farthest-knn graph
+ * (sed_knn_fused_far_f32) -> rowptr [B,N+1], col / val [B, 2 knn N], d [B,N] = rowsum^-1/2 (the dense matrix's 1e-12 background
+ * counted in). Row c: its knn forward entries in the graph's order, then the transposed entries (c, p : c in nn[p]) with p
+ * ascending, each 1/2 (s - 1e-12) d_row d_col; no sort (a bitmap of the transposed pattern is walked row by row), deterministic.
+ * src/smooth_normal_matrix.py:42-92 (construction_affinity_matrix_normal) */
+size_t sed_hpnet_affinity_csr_workspace_bytes(int B, int N, int knn);
+int sed_hpnet_affinity_csr_f32(int B, int N, int knn, float sigma, const float* normals, const int* nn, int* rowptr, int* col,
+                               float* val, float* d, void* ws, size_t ws_bytes, sed_stream_t stream);
 /* ---- batched LOBPCG on the device (the arithmetic inside torch.lobpcg(A, k = 12, niter = 10), src/smooth_normal_matrix.py:198;
  * lobpcg.hip). The search block lives in two caller-owned buffers S, AS [B,N,ld] with columns [X (k) | R (k) | P (k)]. Nothing is
  * copied to the host between the calls of an iteration.

@@ -75,15 +75,15 @@ extern "C" int sed_csr_spmm_f32(int B, int N, int ncol, size_t nnz_stride, const
 //     its TRANSPOSED entries    (c, p) for every p with c in nn[p], p ascending,
 // each with value 1/2 (s - 1e-12) d_row d_col (a pair that is in both lists appears twice, like in the torch build; the product
 // kernel adds them). The transposed half needs no sort: a bitmap T[c][p] (N x N bits per cloud, set with atomicOr -- order-free) is
-// walked row by row, a wave per row, word prefix sums give every set bit its position. Any fixed order is CORRECT (the product
+// walked once per row for word prefix sums (a wave per row); an edge then finds its position as a rank in that row -- one thread per edge. Any fixed order is CORRECT (the product
 // sums a row's entries in storage order, fp32: another order moves the eigenvectors at rounding level, like another lobpcg
 // seed); this one is deterministic. in-degree of the farthest-50 graph is very uneven (periphery points are everybody's farthest
-// neighbour): a row can hold thousands of transposed entries, the walk takes them 64 words at a time.
+// neighbour): a row can hold thousands of transposed entries -- no thread ever walks them.
 namespace {
 
 __global__ __launch_bounds__(256) void aff_rows_kernel(const float* __restrict__ nrm, const int* __restrict__ nn, int N, int knn,
                                                        float inv2s2, float* __restrict__ seff, float* __restrict__ d,
-                                                       int* __restrict__ indeg, unsigned* __restrict__ bitmap, int W) {
+                                                       unsigned* __restrict__ bitmap, int W) {
     const int cloud = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float* nc = nrm + (size_t)cloud * N * 3;
@@ -99,11 +99,34 @@ __global__ __launch_bounds__(256) void aff_rows_kernel(const float* __restrict__
         if (s == 0.f) s = 1e-12f;                                                                                 // :77-80
         so[j] = s;
         rowsum += s;
-        atomicAdd(indeg + (size_t)cloud * N + c, 1);
         atomicOr(bitmap + ((size_t)cloud * N + c) * W + (i >> 5), 1u << (i & 31));
     }
     rowsum += (float)(N - knn) * 1e-12f;
     d[(size_t)cloud * N + i] = 1.0f / sqrtf(rowsum);
+}
+
+// one wave per row of the transposed pattern: exclusive prefix sums of the popcounts of its bitmap words (uint16: N <= 65 535) and
+// the row's in-degree
+__global__ __launch_bounds__(256) void aff_prefix_kernel(const unsigned* __restrict__ bitmap, int N, int W,
+                                                         unsigned short* __restrict__ wprefix, int* __restrict__ indeg) {
+    const int cloud = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const unsigned* bm = bitmap + ((size_t)cloud * N + row) * W;
+    unsigned short* wp = wprefix + ((size_t)cloud * N + row) * W;
+    int run = 0;
+    for (int w0 = 0; w0 < W; w0 += 64) {
+        const int w = w0 + lane;
+        const int cnt = w < W ? __builtin_popcount(bm[w]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (w < W) wp[w] = (unsigned short)(run + incl - cnt);
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) indeg[(size_t)cloud * N + row] = run;
 }
 
 __global__ __launch_bounds__(1024) void aff_rowptr_kernel(const int* __restrict__ indeg, int N, int knn, int* __restrict__ rowptr) {
@@ -127,78 +150,61 @@ __global__ __launch_bounds__(1024) void aff_rowptr_kernel(const int* __restrict_
     for (int r = lo; r < hi; ++r) { acc += knn + in[r]; rp[r + 1] = acc; }
 }
 
+// one thread per graph edge (p, j), c = nn[p][j]: the forward entry of row p and the transposed entry of row c, whose position
+// among row c's transposed entries is the rank of p among the set bits of row c's bitmap
 __global__ __launch_bounds__(256) void aff_fill_kernel(const int* __restrict__ nn, const float* __restrict__ seff,
                                                        const float* __restrict__ d, const unsigned* __restrict__ bitmap,
-                                                       const int* __restrict__ rowptr, int N, int knn, int W, size_t nnz_stride,
-                                                       int* __restrict__ col, float* __restrict__ val) {
-    const int cloud = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= N) return;
-    const int* nc = nn + (size_t)cloud * N * knn;
-    const float* sc = seff + (size_t)cloud * N * knn;
+                                                       const unsigned short* __restrict__ wprefix, const int* __restrict__ rowptr,
+                                                       int N, int knn, int W, size_t nnz_stride, int* __restrict__ col,
+                                                       float* __restrict__ val) {
+    const int cloud = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)N * knn) return;
+    const int p = (int)(e / knn), j = (int)(e - (size_t)p * knn);
+    const int c = nn[(size_t)cloud * N * knn + e];
     const float* dc = d + (size_t)cloud * N;
+    const int* rp = rowptr + (size_t)cloud * (N + 1);
     int* cc = col + (size_t)cloud * nnz_stride;
     float* vv = val + (size_t)cloud * nnz_stride;
-    const int base = rowptr[(size_t)cloud * (N + 1) + row];
-    const float dr = dc[row];
-    for (int j = lane; j < knn; j += 64) {                   // forward entries
-        const int c = nc[(size_t)row * knn + j];
-        cc[base + j] = c;
-        vv[base + j] = 0.5f * (sc[(size_t)row * knn + j] - 1e-12f) * dr * dc[c];
-    }
-    const unsigned* bm = bitmap + ((size_t)cloud * N + row) * W;
-    int pos = base + knn;
-    for (int w0 = 0; w0 < W; w0 += 64) {                     // transposed entries: the set bits of this row's bitmap, ascending
-        const int w = w0 + lane;
-        unsigned word = w < W ? bm[w] : 0u;
-        const int cnt = __builtin_popcount(word);
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        int at = pos + incl - cnt;
-        while (word) {
-            const int p = 32 * w + __builtin_ctz(word);
-            word &= word - 1;
-            const int* np = nc + (size_t)p * knn;
-            int j = 0;
-            while (j < knn - 1 && np[j] != row) ++j;        // the row is among p's neighbours (that is what the bit says)
-            cc[at] = p;
-            vv[at] = 0.5f * (sc[(size_t)p * knn + j] - 1e-12f) * dc[p] * dr;
-            ++at;
-        }
-        pos += __shfl(incl, 63, 64);
-    }
+    const float v = 0.5f * (seff[(size_t)cloud * N * knn + e] - 1e-12f) * dc[p] * dc[c];
+    cc[rp[p] + j] = c;
+    vv[rp[p] + j] = v;
+    const size_t wi = ((size_t)cloud * N + c) * W + (p >> 5);
+    const int rank = wprefix[wi] + __builtin_popcount(bitmap[wi] & ((1u << (p & 31)) - 1u));
+    cc[rp[c] + knn + rank] = p;
+    vv[rp[c] + knn + rank] = v;
 }
 
 }  // namespace
 
-// workspace: s [B,N,knn] f32 | in-degrees [B,N] i32 | bitmap [B,N,ceil(N/32)] u32
+// workspace: s [B,N,knn] f32 | in-degrees [B,N] i32 | bitmap [B,N,ceil(N/32)] u32 | word prefix sums [B,N,ceil(N/32)] u16
 extern "C" size_t sed_hpnet_affinity_csr_workspace_bytes(int B, int N, int knn) {
     if (B <= 0 || N <= 0 || knn <= 0) return 0;
     const size_t W = (size_t)(N + 31) / 32;
     return ((size_t)B * N * knn * sizeof(float) + 255) / 256 * 256 + ((size_t)B * N * sizeof(int) + 255) / 256 * 256 +
-           (size_t)B * N * W * sizeof(unsigned);
+           ((size_t)B * N * W * sizeof(unsigned) + 255) / 256 * 256 + (size_t)B * N * W * sizeof(unsigned short);
 }
 
 // normals [B,N,3] (unit), nn [B,N,knn] (the farthest-knn graph, sed_knn_fused_far_f32) -> rowptr [B,N+1], col / val [B, 2 knn N],
-// d [B,N]: the operator of src/smooth_normal_matrix.py:42-92 as sed_csr_spmm_f32 takes it (A_sym = M + 1e-12 d d^T).
+// d [B,N]: the operator of src/smooth_normal_matrix.py:42-92 as sed_csr_spmm_f32 takes it (A_sym = M + 1e-12 d d^T). N <= 65 535.
 extern "C" int sed_hpnet_affinity_csr_f32(int B, int N, int knn, float sigma, const float* normals, const int* nn, int* rowptr,
                                           int* col, float* val, float* d, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (B <= 0 || N <= 0 || knn <= 0 || knn > N || !(sigma > 0.f) || !normals || !nn || !rowptr || !col || !val || !d || !ws)
         return SED_EINVAL;
+    if (N > 65535) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_hpnet_affinity_csr_workspace_bytes(B, N, knn)) return SED_EINVAL;
     const int W = (N + 31) / 32;
     float* seff = (float*)ws;
     int* indeg = (int*)((uint8_t*)ws + ((size_t)B * N * knn * sizeof(float) + 255) / 256 * 256);
     unsigned* bitmap = (unsigned*)((uint8_t*)indeg + ((size_t)B * N * sizeof(int) + 255) / 256 * 256);
-    hipError_t e = hipMemsetAsync(indeg, 0, (size_t)((uint8_t*)bitmap - (uint8_t*)indeg) + (size_t)B * N * W * sizeof(unsigned), stream);
+    unsigned short* wprefix = (unsigned short*)((uint8_t*)bitmap + ((size_t)B * N * W * sizeof(unsigned) + 255) / 256 * 256);
+    hipError_t e = hipMemsetAsync(bitmap, 0, (size_t)B * N * W * sizeof(unsigned), stream);
     if (e != hipSuccess) return (int)e;
-    aff_rows_kernel<<<dim3((N + 255) / 256, B), 256, 0, stream>>>(normals, nn, N, knn, 1.0f / (2.0f * sigma * sigma), seff, d, indeg,
-                                                                  bitmap, W);
+    aff_rows_kernel<<<dim3((N + 255) / 256, B), 256, 0, stream>>>(normals, nn, N, knn, 1.0f / (2.0f * sigma * sigma), seff, d, bitmap, W);
+    aff_prefix_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(bitmap, N, W, wprefix, indeg);
     aff_rowptr_kernel<<<B, 1024, 0, stream>>>(indeg, N, knn, rowptr);
-    aff_fill_kernel<<<dim3((N + 3) / 4, B), 256, 0, stream>>>(nn, seff, d, bitmap, rowptr, N, knn, W, (size_t)2 * knn * N, col, val);
+    aff_fill_kernel<<<dim3((unsigned)(((size_t)N * knn + 255) / 256), B), 256, 0, stream>>>(nn, seff, d, bitmap, wprefix, rowptr, N, knn, W,
+                                                                                        (size_t)2 * knn * N, col, val);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -39,6 +39,8 @@ SIGNATURES = {
     "sed_knn_pn_fused_f32": (c_int, [c_int, c_int, c_int, c_float, P, P, P, c_size_t, P, P]),
     "sed_knn_fused_far_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_csr_spmm_f32": (c_int, [c_int, c_int, c_int, c_size_t, P, P, P, P, c_int, P, c_int, P]),
+    "sed_hpnet_affinity_csr_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sed_hpnet_affinity_csr_f32": (c_int, [c_int, c_int, c_int, c_float, P, P, P, P, P, P, P, c_size_t, P]),
     "sed_tsgemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sed_tsgemm_tn_f64": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_size_t, P]),
     "sed_ritz_f64": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),

@@ -111,6 +111,28 @@ def knn_farthest(P, k):
     return idx
 
 
+def hpnet_affinity_csr(normals, nn, sigma=0.1, group=16):
+    """normals [B,N,3], nn [B,N,knn] i32 (farthest-knn graph) -> (rowptr [B,N+1] i32, col [B,2 knn N] i32, val f32, d [B,N]): the sparse
+    part of the HPNet affinity operator built by HIP kernels (hpnet_sparse.hip), `group` clouds per call (the transposed
+    pattern's bitmap takes N^2 / 8 bytes per cloud)."""
+    B, N, knn = nn.shape
+    dev = nn.device
+    normals, nn = normals.float().contiguous(), nn.int().contiguous()
+    rowptr = torch.empty((B, N + 1), dtype=torch.int32, device=dev)
+    col = torch.empty((B, 2 * knn * N), dtype=torch.int32, device=dev)
+    val = torch.empty((B, 2 * knn * N), dtype=torch.float32, device=dev)
+    d = torch.empty((B, N), dtype=torch.float32, device=dev)
+    g = min(group, B)
+    nws = lib.sed_hpnet_affinity_csr_workspace_bytes(g, N, knn)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    for b0 in range(0, B, g):
+        nb = min(g, B - b0)
+        check(lib.sed_hpnet_affinity_csr_f32(nb, N, knn, float(sigma), ptr(normals[b0:b0 + nb]), ptr(nn[b0:b0 + nb]), ptr(rowptr[b0:b0 + nb]),
+                                             ptr(col[b0:b0 + nb]), ptr(val[b0:b0 + nb]), ptr(d[b0:b0 + nb]), ptr(ws), nws, stream()),
+              "hpnet_affinity_csr")
+    return rowptr, col, val, d
+
+
 def csr_spmm(rowptr, col, val, X, out=None):
     """Y [B,N,c] = M X for B CSR matrices (rowptr [B,N+1] i32, col / val [B,nnz]) -- the HPNet affinity operator. X / out may
     be column slices [B,N,c] of wider row-major buffers (row stride = ld)."""

@@ -66,28 +66,13 @@ def sparse_affinity(inputs_xyz, N_gt, sigma=0.1, knn=50):
     """The matrix of construction_affinity_matrix_normal (:42-92) without the N x N tensor: CSR of
     M = 1/2 (S + S^T), S_ij = (s_ij - 1e-12) d_i d_j on the farthest-`knn` pattern, and d [B,N] = rowsum^-1/2 with the
     reference's 1e-12 background counted in the row sums; A_sym = M + 1e-12 d d^T.
+    Row c of the CSR: its knn forward entries in the graph's order, then the transposed entries with ascending source point.
     -> (rowptr [B,N+1] i32, col [B,2 knn N] i32, val [B,2 knn N] f32, d [B,N] f32)."""
     from sednet_hip import ops
-    B, N, _ = N_gt.shape
-    nn = ops.knn_farthest(inputs_xyz.contiguous().float(), knn).long()                       # [B,N,k]
-    n_sub = torch.gather(N_gt, 1, nn.reshape(B, N * knn, 1).expand(B, N * knn, 3)).view(B, N, knn, 3)
-    dst = torch.acos((N_gt.unsqueeze(2) * n_sub).sum(-1).clamp(-0.99, 0.99))                # :70
-    s = torch.exp(-dst ** 2 / (2 * sigma * sigma))                                           # [B,N,k]
-    s_eff = torch.where(s == 0, torch.full_like(s, 1e-12), s)                                # zeros -> background (:77-80)
-    rowsum = s_eff.sum(-1) + (N - knn) * 1e-12
-    d = 1.0 / rowsum.sqrt()
-    rows = torch.arange(N, device=nn.device).view(1, N, 1).expand(B, N, knn)
-    v = 0.5 * (s_eff - 1e-12) * d.unsqueeze(-1) * torch.gather(d, 1, nn.reshape(B, -1)).view(B, N, knn)
-    r_all = torch.cat([rows.reshape(B, -1), nn.reshape(B, -1)], 1)                           # forward + transposed entries
-    c_all = torch.cat([nn.reshape(B, -1), rows.reshape(B, -1)], 1)
-    v_all = torch.cat([v.reshape(B, -1), v.reshape(B, -1)], 1)
-    order = torch.sort(r_all * N + c_all, dim=1, stable=True)[1]                             # by (row, col): fixed order
-    r_s = torch.gather(r_all, 1, order)
-    rowptr = torch.zeros(B, N + 1, dtype=torch.int64, device=nn.device)
-    rowptr[:, 1:] = torch.cumsum(torch.zeros(B, N, dtype=torch.int64, device=nn.device).scatter_add_(
-        1, r_s, torch.ones_like(r_s)), 1)
-    return (rowptr.int().contiguous(), torch.gather(c_all, 1, order).int().contiguous(),
-            torch.gather(v_all, 1, order).float().contiguous(), d.float().contiguous())
+    nn = ops.knn_farthest(inputs_xyz.contiguous().float(), knn)                               # [B,N,k] i32
+    # (round 4: acos / exp, row sums, the transposed pattern and the CSR itself in three HIP kernels -- hpnet_sparse.hip; the
+    # torch build this replaces sorted 2 knn N (row, col) keys per cloud and went through gather / scatter_add_ / cumsum)
+    return ops.hpnet_affinity_csr(N_gt, nn, sigma)
 
 
 def affinity_apply(op, X, out=None):

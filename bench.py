@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-k64", action="store_true", help="skip the extra k = 64 measurement")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the one-weight-digit and unstructured legs")
+    ap.add_argument("--hpnet", action="store_true",
+                    help="profiling aid: run the HEADLINE leg with the HPNet stage on (the line's config says so; the default line "
+                         "carries this flow as its `hpnet` leg)")
     return ap.parse_args()
 
 
@@ -387,7 +390,9 @@ def main():
 
     # ---- headline: trained weights, default (fp32-equivalent) arithmetic
     m_type, m_inst = build_models(args.k, dev, "trained")
-    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=args.iterations, dist=dist)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=args.iterations, dist=dist, hpnet=args.hpnet)
+    if args.hpnet:
+        torch.manual_seed(0)
     ops.ms_set_weight_digits(2)
     head = timed(pipe)
     head_sum, cps = leg_summary(head, 2)
@@ -419,7 +424,7 @@ def main():
                                    f"{B} x {N}-point clouds per GPU per batch, k={args.k}, full HIP path "
                                    "(2 SED-Net forwards + guarded mean-shift + primitive LSQ fits + residuals)",
                        "clouds_per_gpu_per_batch": B, "clouds_per_step": clouds_per_step, "points": N, "k": args.k,
-                       "ms_iterations": args.iterations, "embedding_dim": 128,
+                       "ms_iterations": args.iterations, "embedding_dim": 140 if args.hpnet else 128, "hpnet_stage": bool(args.hpnet),
                        "weights": "trained by the reference's training step on synthetic clouds (tests/golden/w_trained.npz)",
                        "ms_weight_digits": 2, "parallelism": f"cloud-shard x{world}",
                        "segments_per_cloud": {"mean": round(float(nl.mean()), 2), "min": int(nl.min()), "max": int(nl.max())},
@@ -476,7 +481,7 @@ def main():
                               "affinity as a sparse operator, 12 leading eigenvectors by a batched LOBPCG that runs in HIP kernels on "
                               "the device (Gram products, Jacobi Ritz solves, block updates: lobpcg.hip), entropy weights; the 140-d "
                               "embedding (padded to 160) goes through the split-fp16 mean-shift kernel instantiated for five feature "
-                              "tiles (dense schedule; the block-sparse kernel exists for d = 128 only)")
+                              "tiles (per cloud block-sparse or key-chunked dense, like at d = 128)")
             hp_sum["x_headline_time_per_cloud"] = round(hp_sum["ms_per_step"] / head_sum["ms_per_step"], 3)
             line["hpnet"] = hp_sum
             del pipe_h

@@ -272,7 +272,7 @@ MS_SPARSE_SKIP = -27.04
 # Threshold of the density probe. Round 2 (planted sigma = 0.01 clusters: near fractions ~0.08) used 0.3. A TRAINED network's
 # embeddings are wider -- near fractions 0.17 .. 0.54 on the 64 bench clouds, the kernel still skips 52 % of the first and 61 % of
 # the second products -- and the block-sparse kernel beats the dense one on every one of them (3.9 ms per cloud in a 64-cloud launch
-# against 5.75; tools/trained_sparse_stats.py); splitting a batch into a sparse and a dense launch costs more than the dense
+# against 5.75; tools/sparse_ab.py, tools/hpnet_ms_ab.py); splitting a batch into a sparse and a dense launch costs more than the dense
 # kernel could win on the widest clouds (134 + 177 ms against 249 ms for all 64 sparse). Unstructured rows sit at 1.0.
 MS_SPARSE_MAX_NEAR = 0.6
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}

@@ -21,8 +21,11 @@ def compute_embedding_loss(pred_feat, gt_label, t_pull=0.5, t_push=1.5):
     # step is otherwise bit-reproducible.)
     B = pred_feat.shape[0]
     dev, dt = pred_feat.device, pred_feat.dtype
-    lab = gt_label - gt_label.min()
-    L = int(lab.max().item()) + 1
+    # label ids are compacted to their rank among the ids present in the batch first: L is then the number of distinct
+    # labels, not the label range -- sparse or large ids (500 apart) would otherwise size the [B, L, L, K] centre differences by the
+    # range (4 GB at L = 500, B = 32, K = 128). torch.unique returns sorted ids: deterministic.
+    uniq, lab = torch.unique(gt_label, return_inverse=True)
+    L = int(uniq.shape[0])
     onehot = (lab[:, None, :] == torch.arange(L, device=dev)[None, :, None]).to(dt)                    # [B, L, M]
     cnt = onehot.sum(2)                                                                                # [B, L]
     present = cnt > 0

@@ -97,6 +97,29 @@ def test_mean_shift_iterations_match_reference(golden):
     np.testing.assert_allclose(snaps[50], g["newX_it50"], atol=1e-5)
 
 
+def test_torch_cpu_twin_of_the_mean_shift_stage_matches_reference(golden):
+    """oracle/torch_cpu.py (bench.py's cpu_baseline times it: the stage on torch CPU tensors, operation by operation as the reference
+    writes it) against the same reference snapshots as the numpy oracle"""
+    import torch
+    from oracle import torch_cpu as otc
+    g = golden("f_ms")
+    X = torch.from_numpy(g["X"])
+    bw = otc.compute_bandwidth(X, 2000, 0.05)
+    np.testing.assert_allclose(float(bw), g["bw_q05_ns2000"], rtol=2e-5)
+    bw = torch.clamp(bw, min=0.003)
+    nx, snaps = X, {}
+    for it in range(1, 51):
+        nx = otc.mean_shift_step(nx, X, bw)
+        if it in (1, 5, 50):
+            snaps[it] = nx.numpy()
+    np.testing.assert_allclose(snaps[1], g["newX_it1"], atol=2e-6)
+    np.testing.assert_allclose(snaps[5][:64], g["newX_it5"], atol=5e-6)
+    np.testing.assert_allclose(snaps[50], g["newX_it50"], atol=1e-5)
+    _, ids, labels = otc.nms(torch.from_numpy(g["newX_it50"]), X, bw)
+    assert len(ids) == 12
+    np.testing.assert_array_equal(mean_shift.canonical_labels(labels.numpy()), mean_shift.canonical_labels(g["nms_labels"]))
+
+
 def test_nms_and_labels_match_reference(golden):
     g = golden("f_ms")
     bw = max(np.float32(g["bw_q05_ns2000"]), np.float32(0.003))

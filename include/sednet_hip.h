@@ -111,8 +111,12 @@ int sed_ms_kth_fused_max_k(int N);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
 /* sampling: first sweep of clouds of >= 8192 points on every fourth key tile (0 = default, or 4) or on every other one (2);
  * results identical (the second sweep verifies the threshold and flags the cloud otherwise) */
+/* tile_coherent = 1: the caller's rows are in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs; kth then
+ * comes back in that order): the second sweep visits, per 128-row block, only the key tiles whose cap can hold a value below the
+ * block's thresholds (triangle inequality on the tiles' unit means, ms_tiles.hip) -- the same K-th values bit for bit, a fraction
+ * of the tiles on clustered rows. Any order is correct with either value. */
 int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                         int* overflow, int sampling, sed_stream_t stream);
+                         int* overflow, int sampling, int tile_coherent, sed_stream_t stream);
 /* `iters` gaussian mean-shift iterations on unit rows, X [B,N,d] -> newX [B,N,d]; bw [B] on device.
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,
@@ -195,8 +199,13 @@ int sed_unsort_rows_f32(int B, int N, int d, const float* in, const int* order, 
  * labels [B,N] in 0..n_centres-1 (ordered by centre index), centre_ids [B,N] (first n_centres[b] valid),
  * n_labels [B] = distinct labels used (the guard loop's test, generate_predictions_aug.py:31). */
 size_t sed_ms_nms_workspace_bytes(int B, int N);
+/* centres_sorted / X_sorted / order (all three or all NULL): the same rows in a tile-coherent order (sorted row i = original row
+ * order[i]; sed_ms_sparse_prepare_f32's order): the membership sweep then visits, per 128-point block, only the centre tiles that
+ * can hold a centre as close as the points' own converged rows -- the same result bit for bit (first-minimum ties by original
+ * index). */
 int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, const float* bw, int* labels,
-                   int* centre_ids, int* n_centres, int* n_labels, void* ws, size_t ws_bytes, sed_stream_t stream);
+                   int* centre_ids, int* n_centres, int* n_labels, void* ws, size_t ws_bytes, const float* centres_sorted,
+                   const float* X_sorted, const int* order, sed_stream_t stream);
 
 /* ---- DGCNN backbone ---------------------------------------------------------------------------------- */
 /* Fused EdgeConv (gather + [x_j - x_i ; x_i] + Conv2d 1x1 + GroupNorm statistics + max over k).

@@ -20,6 +20,9 @@
 #include <type_traits>
 
 int sed_sel_chunks(int B, int N);                    // knn_fused.hip: key chunks of the second sweeps
+size_t ms_tiles_workspace_bytes(int B, int N, int D);                                     // ms_tiles.hip
+int ms_tiles_build(int B, int N, int D, const float* Q, const float* Kr, const uint32_t* Tbuf, void* ws, const unsigned short** list,
+                   const int** count, hipStream_t stream);
 
 namespace {
 
@@ -51,7 +54,11 @@ template <int NT, int PASS, bool F16, bool CHUNK = false, int SAMP = 2>      // 
 __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __restrict__ X, const float* __restrict__ inv,
                                                               int N, int K,
                                                               uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ lists,
-                                                              int* __restrict__ counts, int* __restrict__ overflow) {
+                                                              int* __restrict__ counts, int* __restrict__ overflow,
+                                                              const unsigned short* __restrict__ tlist = nullptr,
+                                                              const int* __restrict__ tcount = nullptr) {
+    // tlist / tcount (sweep 2 only; ms_tiles.hip): the ascending list of key tiles this 128-row block has to visit -- the rows are
+    // in a tile-coherent order and every other tile provably holds no value <= the block's thresholds
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;
@@ -129,13 +136,20 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
     const int tstep = (PASS == 1 && N >= 4096) ? SAMP : 1;
     // few clouds per call: sweep 2 runs gridDim.z key chunks per query block (knn_fused.hip: sed_sel_chunks), one list pair each
     const int zsh = 31 - __builtin_clz(gridDim.z);            // chunk counts are powers of two (sed_sel_chunks): no division
-    const int t0 = CHUNK ? (int)(ntiles * blockIdx.z) >> zsh : 0, t1 = CHUNK ? (int)(ntiles * (blockIdx.z + 1)) >> zsh : ntiles;
-    stage_load(t0);
-    stage_store(0);
+    const bool listed = PASS == 2 && tlist != nullptr;
+    const unsigned short* mytiles = listed ? tlist + ((size_t)cloud * gridDim.x + bxi) * ntiles : nullptr;
+    const int nl = listed ? tcount[(size_t)cloud * gridDim.x + bxi] : ntiles;      // entries of the walk: listed tiles or all of them
+    auto tile_at = [&](int i) { return listed ? (int)mytiles[i] : i; };
+    const int t0 = CHUNK ? (int)(nl * blockIdx.z) >> zsh : 0, t1 = CHUNK ? (int)(nl * (blockIdx.z + 1)) >> zsh : nl;
+    if (t0 < t1) {
+        stage_load(tile_at(t0));
+        stage_store(0);
+    }
     __syncthreads();
     int cur = 0;
-    for (int tile = t0; tile < t1; tile += tstep) {
-        if (tile + tstep < t1) stage_load(tile + tstep);
+    for (int ti = t0; ti < t1; ti += tstep) {
+        const int tile = tile_at(ti);
+        if (ti + tstep < t1) stage_load(tile_at(ti + tstep));
         const float* xt = lds[cur];
         f32x16 s;
         if (F16) {
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
         // (sweep 1 keeps ONE instantiation: with 128 bucket registers a second copy of the network makes the allocator spill)
         if (PASS == 1 || ragged) select(std::true_type{});
         else select(std::false_type{});
-        if (tile + tstep < t1) stage_store(cur ^ 1);
+        if (ti + tstep < t1) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -288,9 +302,10 @@ KWs kcarve(void* ws, int B, int N) {
 }
 
 template <int NT>
-void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, bool quarter, hipStream_t s) {
+int launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, bool quarter, void* tiles_ws, hipStream_t s) {
     const dim3 grid((N + 127) / 128, B);
     constexpr bool F16 = NT == 2 || NT == 4;
+    const float* Xrows = X;                              // the fp32 rows (tile caps)
     if (F16) {
         constexpr int D = F16 ? 32 * NT : 64;
         const size_t rows = (size_t)B * N;
@@ -301,9 +316,16 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
         ms_kth_sweep_kernel<NT, 1, F16, false, 4><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     else
         ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    const unsigned short* tl = nullptr;
+    const int* tc = nullptr;
+    if (tiles_ws) {                                      // rows in a tile-coherent order: sweep 2 walks per-block tile lists
+        const int rc = ms_tiles_build(B, N, 32 * NT, Xrows, Xrows, w.T, tiles_ws, &tl, &tc, s);
+        if (rc != SED_OK) return rc;
+    }
     const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
-    if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
-    else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+    if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow, tl, tc);
+    else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow, tl, tc);
+    return SED_OK;
 }
 
 }  // namespace
@@ -311,35 +333,46 @@ void launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow
 // largest K the fused path takes for clouds of N points
 extern "C" int sed_ms_kth_fused_max_k(int N) { return N >= 4096 ? KMAX_SAMPLED : KMAX; }
 
-extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
+static size_t kth_base_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
     const size_t S = (size_t)sed_sel_chunks(B, N);
     return bn * sizeof(uint32_t) + bn * 2 * S * sizeof(int) + bn * 2 * S * CAPK * sizeof(uint32_t) + 256 +
-           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 256;
+           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 512;
 }
 
-// X [B,N,d] unit rows, d in {32, 64, 96, 128} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
+extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return kth_base_bytes(B, N) + ms_tiles_workspace_bytes(B, N, 160);      // + tile caps and lists (tile_coherent = 1)
+}
+
+// X [B,N,d] unit rows, d in {32, 64, 96, 128, 160} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
 // over j, bit-identical to sed_pairdist_ms_f32 + sed_row_kth_f32. overflow [B] (device ints, zeroed here): overflow[b]
 // becomes 1 if a candidate list of cloud b overflowed (or its threshold fell short): kth[b] is then invalid and the caller
 // must use the materialised path for that cloud. sampling: first sweep of clouds of >= 8192 points on every fourth key tile
 // (0 = default, or 4) or on every other one (2); results identical (the second sweep verifies the threshold).
+// tile_coherent = 1: the caller's rows are in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs): the
+// second sweep then visits, per 128-row block, only the key tiles whose cap can hold a value <= the block's thresholds
+// (ms_tiles.hip) -- same K-th values bit for bit, a fraction of the tiles on clustered rows. Any order is correct with either value.
 extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                                    int* overflow, int sampling, hipStream_t stream) {
+                                    int* overflow, int sampling, int tile_coherent, hipStream_t stream) {
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
-    if (sampling != 0 && sampling != 2 && sampling != 4) return SED_EINVAL;
+    if ((sampling != 0 && sampling != 2 && sampling != 4) || (tile_coherent != 0 && tile_coherent != 1)) return SED_EINVAL;
     const bool quarter = sampling != 2;
     if (d % 32 != 0 || d < 32 || d > 160 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
+    void* tiles_ws = tile_coherent ? (void*)(((uintptr_t)((uint8_t*)ws + kth_base_bytes(B, N)) + 255) & ~(uintptr_t)255) : nullptr;
     hipError_t e = hipMemsetAsync(overflow, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
+    int rc = SED_OK;
     switch (d / 32) {
-        case 1: launch_kth<1>(B, X, w, N, K, overflow, quarter, stream); break;
-        case 2: launch_kth<2>(B, X, w, N, K, overflow, quarter, stream); break;
-        case 3: launch_kth<3>(B, X, w, N, K, overflow, quarter, stream); break;
-        case 4: launch_kth<4>(B, X, w, N, K, overflow, quarter, stream); break;
-        default: launch_kth<5>(B, X, w, N, K, overflow, quarter, stream); break;     // d = 160 (HPNet-widened embedding): exact fp32 products
+        case 1: rc = launch_kth<1>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
+        case 2: rc = launch_kth<2>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
+        case 3: rc = launch_kth<3>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
+        case 4: rc = launch_kth<4>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
+        default: rc = launch_kth<5>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;     // d = 160 (HPNet-widened embedding): exact fp32 products
     }
+    if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
     ms_kth_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, K, rows, N, sed_sel_chunks(B, N), kth,

@@ -21,7 +21,13 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
                                                             const float* __restrict__ X,   // points  [B,N,D]
                                                             const float* __restrict__ cinv,
                                                             const float* __restrict__ xinv,
-                                                            int* __restrict__ member, int N) {
+                                                            int* __restrict__ member, int N,
+                                                            const unsigned short* __restrict__ tlist = nullptr,
+                                                            const int* __restrict__ tcount = nullptr,
+                                                            const int* __restrict__ order = nullptr) {
+    // tlist / tcount / order (ms_tiles.hip): C and X are then in a tile-coherent order (row i = original row order[i]); the block
+    // visits only the listed centre tiles -- no other tile holds a centre as close to any of its points as the point's own
+    // converged row -- and "first minimum" is decided by the ORIGINAL centre index; member is written in original indexing.
     constexpr int D = 32 * NT;
     constexpr int LDX = D + 4;
     constexpr int C4 = D / 4;
@@ -55,6 +61,11 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
     }
     f32x4 stage[NT];
     float stage_ck = 0.f;
+    int stage_oi = 0;
+    __shared__ int ois[2][32];
+    const bool listed = tlist != nullptr;
+    const unsigned short* mytiles = listed ? tlist + ((size_t)cloud * gridDim.x + bxi) * ntiles : nullptr;
+    const int* ordc = listed ? order + (size_t)cloud * N : nullptr;
     auto stage_load = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -66,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
             stage[u] = v;
         }
         if (F16 && tid < 32) { const int key = tile * 32 + tid; stage_ck = key < N ? cinvc[key] : 0.f; }
+        if (listed && tid >= 32 && tid < 64) { const int key = tile * 32 + tid - 32; stage_oi = key < N ? ordc[key] : 0x7fffffff; }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -75,15 +87,21 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
             *(f32x4*)(&lds[buf][row * LDX + 4 * c4]) = stage[u];
         }
         if (F16 && tid < 32) cks[buf][tid] = stage_ck;
+        if (listed && tid >= 32 && tid < 64) ois[buf][tid - 32] = stage_oi;
     };
-    stage_load(0);
-    stage_store(0);
+    const int nl = listed ? tcount[(size_t)cloud * gridDim.x + bxi] : ntiles;
+    auto tile_at = [&](int i) { return listed ? (int)mytiles[i] : i; };
+    if (nl > 0) {
+        stage_load(tile_at(0));
+        stage_store(0);
+    }
     __syncthreads();
     int cur = 0;
     float best = 3.0e38f;
     int besti = 0x7fffffff;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        if (tile + 1 < ntiles) stage_load(tile + 1);
+    for (int ti = 0; ti < nl; ++ti) {
+        const int tile = tile_at(ti);
+        if (ti + 1 < nl) stage_load(tile_at(ti + 1));
         const float* xt = lds[cur];
         f32x16 s;
         if (F16) {
@@ -108,21 +126,32 @@ __global__ __launch_bounds__(256, 2) void membership_kernel(const float* __restr
         // A lane meets its centres in ascending index order (rows ascend with r, tiles with the loop), so "first minimum" is the
         // strict comparison alone; only the cloud's last, partly filled tile tests the index against N.
         const bool ragged = tile * 32 + 32 > N;
+        if (listed) {                 // tile-coherent order: ties between equal distances go to the smaller ORIGINAL centre index
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = tile * 32 + mfma_row(r, hi);
-            const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
-            const float dist = 2.0f - dot2;
-            if (dist < best && (!ragged || ci < N)) { best = dist; besti = ci; }
+            for (int r = 0; r < 16; ++r) {
+                const int ci = tile * 32 + mfma_row(r, hi);
+                const int orig = ois[cur][mfma_row(r, hi)];
+                const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
+                const float dist = 2.0f - dot2;
+                if ((dist < best || (dist == best && orig < besti)) && (!ragged || ci < N)) { best = dist; besti = orig; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = tile * 32 + mfma_row(r, hi);
+                const float dot2 = F16 ? (s[r] * two_cq) * ck4[r >> 2][r & 3] : 2.0f * s[r];
+                const float dist = 2.0f - dot2;
+                if (dist < best && (!ragged || ci < N)) { best = dist; besti = ci; }
+            }
         }
-        if (tile + 1 < ntiles) stage_store(cur ^ 1);
+        if (ti + 1 < nl) stage_store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
     const float ob = xor32(best);
     const int oi = __shfl_xor(besti, 32, 64);
     if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    if (prow < N && hi == 0) member[(size_t)cloud * N + prow] = besti;
+    if (prow < N && hi == 0) member[(size_t)cloud * N + (listed ? ordc[prow] : prow)] = besti;
 }
 
 // ---- 2. histogram -----------------------------------------------------------------------------------
@@ -323,21 +352,36 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const int* __restrict_
 
 }  // namespace
 
-extern "C" size_t sed_ms_nms_workspace_bytes(int B, int N) {
+size_t ms_tiles_workspace_bytes(int B, int N, int D);                                     // ms_tiles.hip
+int ms_tiles_build(int B, int N, int D, const float* Q, const float* Kr, const uint32_t* Tbuf, void* ws, const unsigned short** list,
+                   const int** count, hipStream_t stream);
+
+static size_t nms_base_bytes(int B, int N) {
     // member, counts, uniq, voted, used : 5 int arrays [B,N] ; n_uniq [B] ; split-fp16 row images of the centres and the
     // points (d <= 128) + their row scales for the membership products
     return (size_t)B * N * 5 * sizeof(int) + (size_t)B * sizeof(int) + 512 +
            2 * ((size_t)B * N * sizeof(float) + (size_t)B * N * 128 * sizeof(float) + 256);
 }
 
+extern "C" size_t sed_ms_nms_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return nms_base_bytes(B, N) + 256 + ms_tiles_workspace_bytes(B, N, 160);      // + tile caps and lists (sorted inputs given)
+}
+
 // centres = converged new_X [B,N,d]; X [B,N,d]; bw [B]. Outputs: labels [B,N] int32 (0..m-1, ordered by
 // centre index), centre_ids [B,N] int32 (first n_centres[b] valid, ascending), n_centres [B],
 // n_labels [B] (= number of distinct labels actually used).
+// centres_sorted / X_sorted / order (all three or none): the same rows in a tile-coherent order (row i of the sorted arrays =
+// original row order[i]; sed_ms_sparse_prepare_f32's order): the membership sweep then visits, per 128-point block, only the
+// centre tiles that can hold a centre as close as the points' own converged rows (ms_tiles.hip) -- the same membership bit for bit.
 extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const float* X, const float* bw,
                               int* labels, int* centre_ids, int* n_centres, int* n_labels, void* ws,
-                              size_t ws_bytes, hipStream_t stream) {
+                              size_t ws_bytes, const float* centres_sorted, const float* X_sorted, const int* order,
+                              hipStream_t stream) {
     if (B <= 0 || N <= 0 || !centres || !X || !bw || !labels || !centre_ids || !n_centres || !n_labels || !ws)
         return SED_EINVAL;
+    const bool tiles = centres_sorted != nullptr;
+    if (tiles != (X_sorted != nullptr) || tiles != (order != nullptr)) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 160) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_nms_workspace_bytes(B, N)) return SED_EINVAL;
     const size_t bn = (size_t)B * N;
@@ -353,6 +397,15 @@ extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const f
     if (e != hipSuccess) return (int)e;
 
     dim3 g1((N + 127) / 128, B);
+    const unsigned short* tl = nullptr;
+    const int* tc = nullptr;
+    const float* Cm = tiles ? centres_sorted : centres;      // what the membership sweep reads
+    const float* Xm = tiles ? X_sorted : X;
+    if (tiles) {
+        void* tws = (void*)(((uintptr_t)((uint8_t*)ws + nms_base_bytes(B, N)) + 255) & ~(uintptr_t)255);
+        const int rc = ms_tiles_build(B, N, d, X_sorted, centres_sorted, nullptr, tws, &tl, &tc, stream);
+        if (rc != SED_OK) return rc;
+    }
     if (d == 64 || d == 128) {
         // membership products on the fp16 matrix pipe (split16.h): split the centres and the points once
         float* cinv = (float*)(((uintptr_t)(n_uniq + B) + 255) & ~(uintptr_t)255);
@@ -361,19 +414,19 @@ extern "C" int sed_ms_nms_f32(int B, int N, int d, const float* centres, const f
         h16* ximg = (h16*)(((uintptr_t)(xinv + bn) + 255) & ~(uintptr_t)255);
         const unsigned nb = (unsigned)((bn * (d / 4) + 255) / 256);
         if (d == 64) {
-            split_rows_kernel<64><<<nb, 256, 0, stream>>>(centres, cimg, cinv, bn);
-            split_rows_kernel<64><<<nb, 256, 0, stream>>>(X, ximg, xinv, bn);
-            membership_kernel<2, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N);
+            split_rows_kernel<64><<<nb, 256, 0, stream>>>(Cm, cimg, cinv, bn);
+            split_rows_kernel<64><<<nb, 256, 0, stream>>>(Xm, ximg, xinv, bn);
+            membership_kernel<2, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N, tl, tc, order);
         } else {
-            split_rows_kernel<128><<<nb, 256, 0, stream>>>(centres, cimg, cinv, bn);
-            split_rows_kernel<128><<<nb, 256, 0, stream>>>(X, ximg, xinv, bn);
-            membership_kernel<4, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N);
+            split_rows_kernel<128><<<nb, 256, 0, stream>>>(Cm, cimg, cinv, bn);
+            split_rows_kernel<128><<<nb, 256, 0, stream>>>(Xm, ximg, xinv, bn);
+            membership_kernel<4, true><<<g1, 256, 0, stream>>>((const float*)cimg, (const float*)ximg, cinv, xinv, member, N, tl, tc, order);
         }
     } else {
         switch (d / 32) {
-            case 1: membership_kernel<1, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
-            case 3: membership_kernel<3, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
-            case 5: membership_kernel<5, false><<<g1, 256, 0, stream>>>(centres, X, nullptr, nullptr, member, N); break;
+            case 1: membership_kernel<1, false><<<g1, 256, 0, stream>>>(Cm, Xm, nullptr, nullptr, member, N, tl, tc, order); break;
+            case 3: membership_kernel<3, false><<<g1, 256, 0, stream>>>(Cm, Xm, nullptr, nullptr, member, N, tl, tc, order); break;
+            case 5: membership_kernel<5, false><<<g1, 256, 0, stream>>>(Cm, Xm, nullptr, nullptr, member, N, tl, tc, order); break;
         }
     }
     SED_LAUNCH_CHECK();

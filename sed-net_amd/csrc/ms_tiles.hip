@@ -1,0 +1,176 @@
+// Tile bounds for the N x N sweeps AROUND the mean-shift iterations (round 4): the K-th-distance sweep of the
+// bandwidth (/root/reference/src/mean_shift.py:115-137) and the membership argmin of nms (:139-149) visit every 32-row key tile
+// for every query, although a query's 150 nearest keys / its nearest converged centre lie within ~0.1 rad of it and the rows of
+// a trained network's embedding form clusters 1 rad apart. When the caller hands the rows over in a tile-coherent order (the
+// order ms_sparse_prep.hip produces for the block-sparse iteration kernel: 32-row tiles are cluster-pure), a 128-row workgroup
+// only needs the key tiles whose cap can come within its current radius:
+//     every row of tile t lies within alpha_t of the tile's unit mean m_t (cos alpha_t = the smallest dot product of a row with m_t),
+//     so angle(x, y) >= angle(m_t, m_u) - alpha_t - alpha_u for x in t, y in u (triangle inequality on the unit sphere), and
+//     2 - 2 x.y >= 2 - 2 cos(max(0, that)) =: lb(t, u);
+//     tile u is listed for a workgroup if lb(t, u) <= U_t for one of its four query tiles t, U_t = the largest distance any row of
+//     t still has to look at (bandwidth: the first sweep's threshold T_q, an upper bound of the row's K-th distance; membership: the
+//     distance of a point to its OWN converged row, an upper bound of its distance to the nearest centre).
+// A tile that is not listed cannot hold a candidate <= T_q / a centre as close as the point's own, so the sweeps return exactly
+// what they return over all tiles (tests compare bit for bit). Any row order is correct; the order decides how many tiles are
+// listed (all of them for unstructured rows: U = inf or wide caps). Slack: 1e-4 rad on the angles, 1e-5 on U (the caps and U are
+// fp32 dot products of unit rows, the sweeps' distances split-fp16 products of the same rows: both within 1e-6 of exact).
+#include "common.h"
+
+namespace {
+
+// one wave per 32-row tile: m = normalised mean of its rows (fixed summation order), cosa = min_i r_i . m   (rows past N: ignored)
+__global__ __launch_bounds__(256) void tile_caps_kernel(const float* __restrict__ R, int N, int D, int nt, float* __restrict__ mean,
+                                                        float* __restrict__ cosa) {
+    const int cloud = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= nt) return;
+    const float* Rc = R + (size_t)cloud * N * D;
+    const int r0 = t * 32, r1 = min(N, r0 + 32);
+    float acc[3] = {0.f, 0.f, 0.f};                        // features lane, lane + 64, lane + 128 (D <= 160)
+    for (int r = r0; r < r1; ++r)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (lane + 64 * u < D) acc[u] += Rc[(size_t)r * D + lane + 64 * u];
+    float n2 = acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+    const float inv = n2 > 0.f ? 1.0f / sqrtf(n2) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) acc[u] *= inv;
+    float* mo = mean + ((size_t)cloud * nt + t) * D;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (lane + 64 * u < D) mo[lane + 64 * u] = acc[u];
+    float cmin = 1.0f;
+    for (int r = r0; r < r1; ++r) {
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (lane + 64 * u < D) dot = fmaf(Rc[(size_t)r * D + lane + 64 * u], acc[u], dot);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        cmin = fminf(cmin, dot);
+    }
+    if (lane == 0) cosa[(size_t)cloud * nt + t] = inv > 0.f ? cmin : -1.0f;      // a zero mean covers nothing: cap = the whole sphere
+}
+
+// per 32-row QUERY tile: U_t. MODE 0 (bandwidth): max over its rows of the first sweep's threshold (Tbuf: order-preserving
+// uint image of the float, 0xFFFFFFFF = none found); MODE 1 (membership): max over its points of 2 - 2 x_i . c_i
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_radius_kernel(const uint32_t* __restrict__ Tbuf, const float* __restrict__ X,
+                                                          const float* __restrict__ C, int N, int D, int nt, float* __restrict__ U) {
+    const int cloud = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= nt) return;
+    const int r0 = t * 32, r1 = min(N, r0 + 32);
+    float u = 0.f;
+    if (MODE == 0) {
+        const int r = r0 + (lane & 31);
+        if (r < r1) {
+            const uint32_t k = Tbuf[(size_t)cloud * N + r];
+            u = k == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(k);
+        }
+    } else {
+        const float* Xc = X + (size_t)cloud * N * D;
+        const float* Cc = C + (size_t)cloud * N * D;
+        for (int r = r0; r < r1; ++r) {
+            float dot = 0.f;
+            for (int c = lane; c < D; c += 64) dot = fmaf(Xc[(size_t)r * D + c], Cc[(size_t)r * D + c], dot);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            const float dv = 2.0f - 2.0f * dot;
+            u = fmaxf(u, dv == dv ? dv : __builtin_inff());              // NaN rows: everything is listed
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) u = fmaxf(u, __shfl_xor(u, off, 64));
+    if (lane == 0) U[(size_t)cloud * nt + t] = u;
+}
+
+// one workgroup per (128-row query block, cloud): the ascending list of key tiles it needs. mq / cq: caps of the query side's
+// tiles, mk / ck: of the key side's (the same arrays for the bandwidth). list [B, nbx, lstride] u16, count [B, nbx].
+__global__ __launch_bounds__(256) void tile_lists_kernel(const float* __restrict__ mq, const float* __restrict__ cq,
+                                                         const float* __restrict__ mk, const float* __restrict__ ck,
+                                                         const float* __restrict__ U, int D, int nt, int nbx, int lstride,
+                                                         unsigned short* __restrict__ list, int* __restrict__ count) {
+    __shared__ float qm[4][160];
+    __shared__ float qa[4], qu[4];
+    __shared__ int wsum[4], base_s;
+    const int cloud = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * D; i += 256) {
+        const int w = i / D, c = i - w * D, t = 4 * bx + w;
+        qm[w][c] = t < nt ? mq[((size_t)cloud * nt + t) * D + c] : 0.f;
+    }
+    if (tid < 4) {
+        const int t = 4 * bx + tid;
+        qa[tid] = t < nt ? acosf(fminf(fmaxf(cq[(size_t)cloud * nt + t], -1.0f), 1.0f)) : 0.f;
+        qu[tid] = t < nt ? U[(size_t)cloud * nt + t] * 1.00001f + 1.0e-5f : -1.0f;        // -1: a tile past the end needs nothing
+    }
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    unsigned short* lo = list + ((size_t)cloud * nbx + bx) * lstride;
+    for (int u0 = 0; u0 < nt; u0 += 256) {
+        const int u = u0 + tid;
+        bool need = false;
+        if (u < nt) {
+            const float* m = mk + ((size_t)cloud * nt + u) * D;
+            const float au = acosf(fminf(fmaxf(ck[(size_t)cloud * nt + u], -1.0f), 1.0f));
+            float dot[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < D; ++c) {
+                const float v = m[c];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) dot[w] = fmaf(qm[w][c], v, dot[w]);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float ang = acosf(fminf(fmaxf(dot[w], -1.0f), 1.0f)) - qa[w] - au - 1.0e-4f;
+                const float lb = ang > 0.f ? 2.0f - 2.0f * cosf(ang) : 0.f;
+                need = need || !(lb > qu[w]);                // (NaN caps: listed)
+            }
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+        if (lane == 0) wsum[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int at = base_s;
+        for (int w = 0; w < wave; ++w) at += wsum[w];
+        if (need) lo[at + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (unsigned short)u;
+        __syncthreads();
+        if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[(size_t)cloud * nbx + bx] = base_s;
+}
+
+}  // namespace
+
+// workspace of the tile lists of one sweep: caps of the query side and of the key side, U, lists, counts
+size_t ms_tiles_workspace_bytes(int B, int N, int D) {
+    const size_t nt = (size_t)(N + 31) / 32, nbx = (size_t)(N + 127) / 128;
+    return 2 * (((size_t)B * nt * D * sizeof(float) + 255) / 256 * 256) + 3 * (((size_t)B * nt * sizeof(float) + 255) / 256 * 256) +
+           ((size_t)B * nbx * nt * sizeof(unsigned short) + 255) / 256 * 256 + ((size_t)B * nbx * sizeof(int) + 255) / 256 * 256;
+}
+
+// Builds the lists into `ws` (ms_tiles_workspace_bytes). Q / Kr: the query side's and the key side's fp32 rows [B,N,D] in the
+// tile-coherent order (Kr == Q for the bandwidth); Tbuf != NULL: bandwidth mode (radius from the first sweep's thresholds),
+// otherwise membership mode (radius from 2 - 2 Q_i . Kr_i). -> *list [B, nbx, nt] u16, *count [B, nbx] inside ws.
+int ms_tiles_build(int B, int N, int D, const float* Q, const float* Kr, const uint32_t* Tbuf, void* ws, const unsigned short** list,
+                   const int** count, hipStream_t stream) {
+    const int nt = (N + 31) / 32, nbx = (N + 127) / 128;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    uint8_t* p = (uint8_t*)ws;
+    float* mq = (float*)p; p += up((size_t)B * nt * D * sizeof(float));
+    float* mk = (float*)p; p += up((size_t)B * nt * D * sizeof(float));
+    float* cq = (float*)p; p += up((size_t)B * nt * sizeof(float));
+    float* ck = (float*)p; p += up((size_t)B * nt * sizeof(float));
+    float* U = (float*)p; p += up((size_t)B * nt * sizeof(float));
+    unsigned short* lst = (unsigned short*)p; p += up((size_t)B * nbx * nt * sizeof(unsigned short));
+    int* cnt = (int*)p;
+    const dim3 gt((nt + 3) / 4, B);
+    tile_caps_kernel<<<gt, 256, 0, stream>>>(Q, N, D, nt, mq, cq);
+    if (Kr != Q) tile_caps_kernel<<<gt, 256, 0, stream>>>(Kr, N, D, nt, mk, ck);
+    if (Tbuf) tile_radius_kernel<0><<<gt, 256, 0, stream>>>(Tbuf, nullptr, nullptr, N, D, nt, U);
+    else tile_radius_kernel<1><<<gt, 256, 0, stream>>>(nullptr, Q, Kr, N, D, nt, U);
+    tile_lists_kernel<<<dim3(nbx, B), 256, 0, stream>>>(mq, cq, Kr != Q ? mk : mq, Kr != Q ? ck : cq, U, D, nt, nbx, nt, lst, cnt);
+    SED_LAUNCH_CHECK();
+    *list = lst;
+    *count = cnt;
+    return SED_OK;
+}

@@ -218,10 +218,25 @@ KTH_FUSED_MIN_BLOCKS = 0        # the fused path wins at every batch size since 
 KTH_SAMPLING = 0                # first bandwidth sweep of clouds of >= 8192 points: 0 / 4 = every fourth key tile, 2 = every other
 
 
-def ms_bandwidth(X, K, min_bw=0.003):
+MS_TILES = True          # bandwidth / membership sweeps on per-block tile lists when a tile-coherent row order is at hand (ms_tiles.hip)
+
+
+def ms_prep_ok(X):
+    """can ms_sparse_prepare order these rows (the block-sparse kernel's range: d = 128 / 160, 1024 <= N <= 16384)?"""
+    return X.shape[2] in (128, 160) and 1024 <= X.shape[1] <= 16384
+
+
+def prep_select(prep, idx):
+    """the preparation of a subset of the clouds (idx: device int64 tensor)"""
+    return {k: v[idx].contiguous() for k, v in prep.items()}
+
+
+def ms_bandwidth(X, K, min_bw=0.003, prep=None):
     """X [B,n,D] unit rows (padded) -> bw [B] = max(mean_i sqrt(max(K-th smallest of 2-2x_i.x_j, 1e-6)), min_bw)
-    (src/mean_shift.py:115-137 and the clamp at :34)."""
+    (src/mean_shift.py:115-137 and the clamp at :34). prep = ms_sparse_prepare(X) (optional): the fused sweeps then run on the
+    sorted rows and their second sweep only visits the key tiles near each 128-row block -- the same K-th values bit for bit."""
     B, N, D = X.shape
+    tiles = prep is not None and MS_TILES
     if K < 1 or K > N:
         raise RuntimeError(f"selected index k out of range (K={K}, rows={N})")   # torch.topk's error in the reference
     kth = torch.empty((B, N), dtype=torch.float32, device=X.device)
@@ -233,8 +248,11 @@ def ms_bandwidth(X, K, min_bw=0.003):
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
         flag = torch.empty((B,), dtype=torch.int32, device=X.device)
-        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), int(KTH_SAMPLING), stream()),
-              "ms_kth_fused")
+        kth_s = torch.empty_like(kth) if tiles else kth
+        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(prep["Xs"] if tiles else X), ptr(kth_s), ptr(ws), nbytes, ptr(flag),
+                                       int(KTH_SAMPLING), 1 if tiles else 0, stream()), "ms_kth_fused")
+        if tiles:                                            # back to the caller's row order: the mean below sums in that order
+            kth.scatter_(1, prep["order"].long(), kth_s)
         todo = torch.nonzero(flag.cpu()).squeeze(1)         # one small D->H copy
         FUSED_STATS["fused"] += B - todo.numel()
         FUSED_STATS["fallback"] += todo.numel()
@@ -396,24 +414,28 @@ def ms_iterate_sparse(X, bw, iters, skip_below=-30.0, n_pivots=64, margin=2e-3, 
     return ms_sparse_run(ms_sparse_prepare(X, n_pivots), bw, iters, skip_below, margin, stats)
 
 
-def ms_iterate(X, bw, iters):
-    """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79)."""
+def ms_iterate(X, bw, iters, prep=None):
+    """X [B,N,D], bw [B] -> new_X [B,N,D] after `iters` mean-shift iterations (src/mean_shift.py:45-79).
+    prep: ms_sparse_prepare(X) if the caller already has it (the bandwidth and nms sweeps use the same order)."""
     B, N, D = X.shape
+    sparse_all = (lambda: ms_sparse_run(prep, bw, iters, MS_SPARSE_SKIP)) if prep is not None else \
+                 (lambda: ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP))
     if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D in (128, 160) and iters > 0 and 1024 <= N <= 16384:
         if MS_SPARSE == "on":
-            return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+            return sparse_all()
         sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < MS_SPARSE_MAX_NEAR).cpu()       # one small D->H copy
         ns = int(sparse.sum())
         MS_SPARSE_STATS["sparse_clouds"] += ns
         MS_SPARSE_STATS["dense_clouds"] += B - ns
         if ns == B:
-            return ms_iterate_sparse(X, bw, iters, MS_SPARSE_SKIP)
+            return sparse_all()
         if ns == 0:
             return _ms_iterate_dense_by_cloud(X, bw, iters)
         si = torch.nonzero(sparse).squeeze(1).to(X.device)
         di = torch.nonzero(~sparse).squeeze(1).to(X.device)
         out = torch.empty_like(X)
-        out[si] = ms_iterate_sparse(X[si], bw[si].contiguous(), iters, MS_SPARSE_SKIP)
+        out[si] = (ms_sparse_run(prep_select(prep, si), bw[si].contiguous(), iters, MS_SPARSE_SKIP) if prep is not None else
+                   ms_iterate_sparse(X[si], bw[si].contiguous(), iters, MS_SPARSE_SKIP))
         out[di] = _ms_iterate_dense_by_cloud(X[di], bw[di].contiguous(), iters)
         return out
     return _ms_iterate_dense(X, bw, iters)
@@ -463,10 +485,14 @@ def ms_set_variant(variant):
     config_changed()
 
 
-def ms_nms(centres, X, bw):
+def ms_nms(centres, X, bw, prep=None):
     """-> labels [B,N] i32, centre_ids [B,N] i32, n_centres [B] i32, n_labels [B] i32
-    (src/mean_shift.py:139-179)."""
+    (src/mean_shift.py:139-179). prep = ms_sparse_prepare(X) (optional): the membership sweep then runs in the sorted order on
+    per-block tile lists -- the same membership bit for bit."""
     B, N, D = X.shape
+    tiles = prep is not None and MS_TILES
+    if tiles:
+        Cs = torch.gather(centres, 1, prep["order"].long().unsqueeze(-1).expand(B, N, D)).contiguous()
     dev = X.device
     labels = torch.empty((B, N), dtype=torch.int32, device=dev)
     ids = torch.empty((B, N), dtype=torch.int32, device=dev)
@@ -475,7 +501,8 @@ def ms_nms(centres, X, bw):
     nbytes = lib.sed_ms_nms_workspace_bytes(B, N)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     check(lib.sed_ms_nms_f32(B, N, D, ptr(centres), ptr(X), ptr(bw), ptr(labels), ptr(ids), ptr(n_c), ptr(n_l),
-                             ptr(ws), nbytes, stream()), "ms_nms")
+                             ptr(ws), nbytes, ptr(Cs) if tiles else None, ptr(prep["Xs"]) if tiles else None,
+                             ptr(prep["order"]) if tiles else None, stream()), "ms_nms")
     return labels, ids, n_c, n_l
 
 

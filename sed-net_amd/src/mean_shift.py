@@ -88,6 +88,10 @@ class MeanShift:
         n_centres [B] i32, n_labels [B] i32); nothing is copied to the host."""
         B, N, d = X.shape
         Xp = ops.pad_features(X)
+        # one tile-coherent row order per cloud (a function of X alone) serves all three stages: the bandwidth's and the nms
+        # membership's sweeps skip the key tiles that provably hold nothing for a 128-row block, the block-sparse iteration kernel
+        # runs on the sorted rows
+        prep = ops.ms_sparse_prepare(Xp) if (ops.ms_prep_ok(Xp) and ops.MS_SPARSE != "off" and ops._MS_VARIANT == "auto") else None
         if bw is None:
             K = int(quantile * num_samples)
             if num_samples >= N:
@@ -97,14 +101,14 @@ class MeanShift:
                 if self.match_rng:
                     for _ in range(B):
                         self._subset(N, num_samples, "cpu")
-                Xs = Xp
+                Xs, bprep = Xp, prep
             else:
                 # one subset per cloud, drawn cloud by cloud like the reference's per-cloud calls
                 sub = torch.stack([self._subset(N, num_samples, X.device) for _ in range(B)])
-                Xs = torch.gather(Xp, 1, sub.unsqueeze(-1).expand(B, num_samples, Xp.shape[2]))
-            bw = ops.ms_bandwidth(Xs.contiguous(), K, 0.003)
-        new_Xp = ops.ms_iterate(Xp, bw, iterations)
-        labels, ids, n_c, n_l = ops.ms_nms(new_Xp, Xp, bw)
+                Xs, bprep = torch.gather(Xp, 1, sub.unsqueeze(-1).expand(B, num_samples, Xp.shape[2])), None
+            bw = ops.ms_bandwidth(Xs.contiguous(), K, 0.003, prep=bprep)
+        new_Xp = ops.ms_iterate(Xp, bw, iterations, prep=prep)
+        labels, ids, n_c, n_l = ops.ms_nms(new_Xp, Xp, bw, prep=prep)
         return new_Xp[:, :, :d], bw, labels, ids, n_c, n_l
 
     def guard_mean_shift_batch(self, X, quantile, iterations, num_samples=10000, factor=1.2, max_clusters=49,

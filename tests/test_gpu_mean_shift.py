@@ -334,12 +334,12 @@ def test_fused_kth_distance_is_bit_identical(T, N, d, K, B):
     nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
     ws = T.empty((nbytes,), dtype=T.uint8, device="cuda")
     flag = T.empty((B,), dtype=T.int32, device="cuda")
-    check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, stream()), "kth_fused")
+    check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, 0, stream()), "kth_fused")
     assert int(flag.sum()) == 0
     kth_2 = T.empty_like(kth_f)                                         # the other first-sweep sampling stride: same values
-    check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_2), ptr(ws), nbytes, ptr(flag), 2, stream()), "kth_fused")
+    check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_2), ptr(ws), nbytes, ptr(flag), 2, 0, stream()), "kth_fused")
     assert int(flag.sum()) == 0 and T.equal(kth_2, kth_f)
-    assert lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_2), ptr(ws), nbytes, ptr(flag), 3, stream()) == -1
+    assert lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth_2), ptr(ws), nbytes, ptr(flag), 3, 0, stream()) == -1
     ld = (N + 3) // 4 * 4
     mat = T.empty((B, N, ld), dtype=T.float32, device="cuda")
     kth_m = T.empty((B, N), dtype=T.float32, device="cuda")
@@ -348,11 +348,11 @@ def test_fused_kth_distance_is_bit_identical(T, N, d, K, B):
     assert T.equal(kth_f, kth_m)
     kmax = lib.sed_ms_kth_fused_max_k(N)
     assert kmax == (224 if N >= 4096 else 160)
-    assert lib.sed_ms_kth_fused_f32(B, N, D, kmax + 1, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, stream()) == -2
+    assert lib.sed_ms_kth_fused_f32(B, N, D, kmax + 1, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, 0, stream()) == -2
     if N >= 4096 and K < 161:
         # the guard retries' K (quantile x 1.2, x 1.44): sampled first sweep with the 6-sigma rank, verified by the second
         for K2 in (int(K * 1.2), min(int(K * 1.44), kmax)):
-            check(lib.sed_ms_kth_fused_f32(B, N, D, K2, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, stream()), "kth_fused")
+            check(lib.sed_ms_kth_fused_f32(B, N, D, K2, ptr(X), ptr(kth_f), ptr(ws), nbytes, ptr(flag), 0, 0, stream()), "kth_fused")
             if int(flag.sum()) == 0:                                   # a raised flag only sends the caller to the other path
                 check(lib.sed_row_kth_f32(B, N, ld, K2, ptr(mat), ptr(kth_m), stream()), "row_kth")
                 assert T.equal(kth_f, kth_m)
@@ -772,3 +772,45 @@ def test_hpnet_width_runs_the_split_fp16_kernels(T):
         np.testing.assert_allclose(res[v][0][rows], ref, atol=3e-6, err_msg=v)
     np.testing.assert_array_equal(bad[1], bad_ref[1])                       # flagged cloud: the exact fp32 kernel's bits
     np.testing.assert_allclose(bad[0], bad_ref[0], atol=1e-5)
+
+
+@pytest.mark.parametrize("d", [128, 140])
+def test_tile_lists_change_neither_bandwidth_nor_membership(T, d):
+    """Round 4 (ms_tiles.hip): with a tile-coherent row order at hand (ms_sparse_prepare) the bandwidth's second sweep and the nms
+    membership sweep visit only the key tiles near each 128-row block. A skipped tile provably holds no candidate, so everything is
+    bit-identical to the sweeps over all tiles: bandwidths (the mean of the per-row K-th distances, summed in the caller's row
+    order), labels, centre ids and counts -- on clustered rows (few tiles listed), on an unstructured cloud (all tiles listed),
+    ragged N, d = 128 (split-fp16 products) and d = 140 -> 160 (exact fp32 products), also with a guard-retry K."""
+    from sednet_hip import ops, synth
+    N = 5003
+    Xs = [synth.clustered_embedding(N=N, d=d, n_clusters=7 + 3 * c, sigma=0.02, seed=900 + c)[0] for c in range(3)]
+    rnd = T.nn.functional.normalize(T.randn(N, d, generator=T.Generator().manual_seed(4)), dim=1).numpy()
+    X = ops.pad_features(dev(T, np.stack(Xs + [rnd])))
+    prep = ops.ms_sparse_prepare(X)
+    for K in (75, 108):
+        a = ops.ms_bandwidth(X, K, 0.003)
+        b = ops.ms_bandwidth(X, K, 0.003, prep=prep)
+        assert T.equal(a, b), (K, a, b)
+    bw = ops.ms_bandwidth(X, 75, 0.003, prep=prep)
+    new_X = ops.ms_iterate(X, bw, 30, prep=prep)
+    assert T.equal(new_X, ops.ms_iterate(X, bw, 30))                          # a given row order or the kernel's own: the same rows
+    ref = ops.ms_nms(new_X, X, bw)
+    got = ops.ms_nms(new_X, X, bw, prep=prep)
+    for r, g_, name in zip(ref, got, ("labels", "centre ids", "centres", "labels used")):
+        assert T.equal(r, g_), name
+    assert 5 <= int(got[2][0]) <= 12 and int(got[2][3]) >= 1
+    # ties between bit-identical centres go to the smaller ORIGINAL index in either order: duplicate converged rows
+    dup = new_X.clone()
+    dup[:, 1::2] = dup[:, 0:-1:2]
+    for r, g_ in zip(ops.ms_nms(dup, X, bw), ops.ms_nms(dup, X, bw, prep=prep)):
+        assert T.equal(r, g_)
+    try:                                                                      # and the whole stage through the mirror, lists on / off
+        from src.mean_shift import MeanShift
+        ms = MeanShift()
+        on = ms.mean_shift_batch(X[:, :, :d], 10000, 0.015, 20)
+        ops.MS_TILES = False
+        off = ms.mean_shift_batch(X[:, :, :d], 10000, 0.015, 20)
+    finally:
+        ops.MS_TILES = True
+    for a_, b_ in zip(on, off):
+        assert T.equal(a_, b_)

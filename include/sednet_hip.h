@@ -111,12 +111,13 @@ int sed_ms_kth_fused_max_k(int N);
 size_t sed_ms_kth_fused_workspace_bytes(int B, int N);
 /* sampling: first sweep of clouds of >= 8192 points on every fourth key tile (0 = default, or 4) or on every other one (2);
  * results identical (the second sweep verifies the threshold and flags the cloud otherwise) */
-/* tile_coherent = 1: the caller's rows are in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs; kth then
- * comes back in that order): the second sweep visits, per 128-row block, only the key tiles whose cap can hold a value below the
- * block's thresholds (triangle inequality on the tiles' unit means, ms_tiles.hip) -- the same K-th values bit for bit, a fraction
- * of the tiles on clustered rows. Any order is correct with either value. */
+/* X_sorted / order (both or both NULL): the same rows in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs
+ * and order: sorted row i = row order[i]): the second sweep then runs on them and visits, per 128-row block, only the key tiles whose
+ * cap can hold a value below the block's thresholds (triangle inequality on the tiles' unit means, ms_tiles.hip) -- the same K-th
+ * values bit for bit (kth stays in X's row order), a fraction of the tiles on clustered rows. The first sweep keeps the caller's
+ * order: its sampled threshold assumes a row's nearest keys are spread over the key tiles. */
 int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                         int* overflow, int sampling, int tile_coherent, sed_stream_t stream);
+                         int* overflow, int sampling, const float* X_sorted, const int* order, sed_stream_t stream);
 /* `iters` gaussian mean-shift iterations on unit rows, X [B,N,d] -> newX [B,N,d]; bw [B] on device.
  * src/mean_shift.py:45-79 (mean_shift_), src/guard.py:7-9 */
 int sed_ms_iterate_f32(int B, int N, int d, int iters, const float* bw, const float* X, float* newX,

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void ms_kth_sweep_kernel(const float* __res
 // value) or of more than the 2 CAPK register slots raises the cloud's flag.
 __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __restrict__ lists,
                                                               const int* __restrict__ counts, int K, size_t rows, int N,
-                                                              int S, float* __restrict__ kth, int* __restrict__ overflow) {
+                                                              int S, float* __restrict__ kth, int* __restrict__ overflow,
+                                                              const int* __restrict__ order = nullptr) {
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -285,10 +286,18 @@ __global__ __launch_bounds__(256) void ms_kth_finalize_kernel(const uint32_t* __
         for (int u = 0; u < NV; ++u) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v[u] <= mid));
         if (c >= K) hiv = mid; else lo = mid + 1;
     }
-    if (lane == 0) kth[row] = sortable_f32(lo);
+    // (order: the sweeps ran on rows in a tile-coherent order, sorted row i = the caller's row order[i] of the same cloud)
+    if (lane == 0) kth[order ? (row / (size_t)N) * N + order[row] : row] = sortable_f32(lo);
 }
 
-struct KWs { uint32_t* T; int* counts; uint32_t* lists; float* inv; h16* img; };
+// thresholds of the first sweep (caller's row order) -> the tile-coherent order of the second sweep
+__global__ void kth_gather_T_kernel(const uint32_t* __restrict__ T, const int* __restrict__ order, size_t rows, int N,
+                                    uint32_t* __restrict__ Ts) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) Ts[i] = T[(i / (size_t)N) * N + order[i]];
+}
+
+struct KWs { uint32_t* T; int* counts; uint32_t* lists; float* inv; h16* img; uint32_t* T2; float* inv2; h16* img2; };
 KWs kcarve(void* ws, int B, int N) {
     const size_t bn = (size_t)B * N;
     KWs w;
@@ -298,33 +307,55 @@ KWs kcarve(void* ws, int B, int N) {
     w.lists = (uint32_t*)(((uintptr_t)(w.counts + 2 * S * bn) + 15) & ~(uintptr_t)15);
     w.inv = (float*)(w.lists + bn * 2 * S * CAPK);
     w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
+    // the second sweep's own thresholds / row scales / row image when it runs on the sorted rows
+    w.T2 = (uint32_t*)(((uintptr_t)(w.img + bn * 2 * 128) + 255) & ~(uintptr_t)255);
+    w.inv2 = (float*)(w.T2 + bn);
+    w.img2 = (h16*)(((uintptr_t)(w.inv2 + bn) + 255) & ~(uintptr_t)255);
     return w;
 }
 
+// Xs / order != NULL: the SECOND sweep runs on Xs (the same rows in a tile-coherent order, sorted row i = row order[i]) and walks
+// per-block tile lists (ms_tiles.hip). The FIRST sweep always runs on the caller's order: its threshold for the guard retries' K
+// and for large clouds samples every 2nd / 4th key tile and relies on a row's nearest keys being spread over the tiles like a
+// binomial -- in a cluster-sorted order they sit in a handful of consecutive tiles, the sampled count swings by whole tiles, the
+// threshold falls short and the cloud drops to the materialised path (measured: 20 ms per step). A threshold is a property of
+// the row, not of the order, so it is simply carried over.
 template <int NT>
-int launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, bool quarter, void* tiles_ws, hipStream_t s) {
+int launch_kth(int B, const float* X, const KWs& w, int N, int K, int* overflow, bool quarter, const float* Xs, const int* order,
+               void* tiles_ws, hipStream_t s) {
     const dim3 grid((N + 127) / 128, B);
     constexpr bool F16 = NT == 2 || NT == 4;
-    const float* Xrows = X;                              // the fp32 rows (tile caps)
+    constexpr int D = 32 * NT;
+    const size_t rows = (size_t)B * N;
+    const float* X1 = X;
     if (F16) {
-        constexpr int D = F16 ? 32 * NT : 64;
-        const size_t rows = (size_t)B * N;
-        split_rows_kernel<D><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
-        X = (const float*)w.img;
+        split_rows_kernel<F16 ? D : 64><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(X, w.img, w.inv, rows);
+        X1 = (const float*)w.img;
     }
     if (N >= 8192 && K <= KMAX && quarter)      // (larger K: 128 bucket values saturate, T loosens, the lists overflow)
-        ms_kth_sweep_kernel<NT, 1, F16, false, 4><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+        ms_kth_sweep_kernel<NT, 1, F16, false, 4><<<grid, 256, 0, s>>>(X1, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     else
-        ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow);
+        ms_kth_sweep_kernel<NT, 1, F16><<<grid, 256, 0, s>>>(X1, w.inv, N, K, w.T, w.lists, w.counts, overflow);
     const unsigned short* tl = nullptr;
     const int* tc = nullptr;
-    if (tiles_ws) {                                      // rows in a tile-coherent order: sweep 2 walks per-block tile lists
-        const int rc = ms_tiles_build(B, N, 32 * NT, Xrows, Xrows, w.T, tiles_ws, &tl, &tc, s);
+    const float* X2 = X1;
+    const float* inv2 = w.inv;
+    uint32_t* T2 = w.T;
+    if (Xs) {
+        kth_gather_T_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(w.T, order, rows, N, w.T2);
+        T2 = w.T2;
+        X2 = Xs;
+        if (F16) {
+            split_rows_kernel<F16 ? D : 64><<<(unsigned)((rows * (D / 4) + 255) / 256), 256, 0, s>>>(Xs, w.img2, w.inv2, rows);
+            X2 = (const float*)w.img2;
+            inv2 = w.inv2;
+        }
+        const int rc = ms_tiles_build(B, N, D, Xs, Xs, T2, tiles_ws, &tl, &tc, s);
         if (rc != SED_OK) return rc;
     }
     const dim3 grid2(grid.x, grid.y, sed_sel_chunks(B, N));
-    if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow, tl, tc);
-    else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X, w.inv, N, K, w.T, w.lists, w.counts, overflow, tl, tc);
+    if (grid2.z > 1) ms_kth_sweep_kernel<NT, 2, F16, true><<<grid2, 256, 0, s>>>(X2, inv2, N, K, T2, w.lists, w.counts, overflow, tl, tc);
+    else ms_kth_sweep_kernel<NT, 2, F16><<<grid, 256, 0, s>>>(X2, inv2, N, K, T2, w.lists, w.counts, overflow, tl, tc);
     return SED_OK;
 }
 
@@ -337,12 +368,12 @@ static size_t kth_base_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
     const size_t S = (size_t)sed_sel_chunks(B, N);
     return bn * sizeof(uint32_t) + bn * 2 * S * sizeof(int) + bn * 2 * S * CAPK * sizeof(uint32_t) + 256 +
-           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 512;
+           2 * (bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image*/ + 512) + bn * sizeof(uint32_t) + 512;
 }
 
 extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return kth_base_bytes(B, N) + ms_tiles_workspace_bytes(B, N, 160);      // + tile caps and lists (tile_coherent = 1)
+    return kth_base_bytes(B, N) + ms_tiles_workspace_bytes(B, N, 160);      // + tile caps and lists (X_sorted given)
 }
 
 // X [B,N,d] unit rows, d in {32, 64, 96, 128, 160} -> kth [B,N] = K-th smallest (1-based, self included) of 2 - 2 x_i.x_j
@@ -350,33 +381,34 @@ extern "C" size_t sed_ms_kth_fused_workspace_bytes(int B, int N) {
 // becomes 1 if a candidate list of cloud b overflowed (or its threshold fell short): kth[b] is then invalid and the caller
 // must use the materialised path for that cloud. sampling: first sweep of clouds of >= 8192 points on every fourth key tile
 // (0 = default, or 4) or on every other one (2); results identical (the second sweep verifies the threshold).
-// tile_coherent = 1: the caller's rows are in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs): the
-// second sweep then visits, per 128-row block, only the key tiles whose cap can hold a value <= the block's thresholds
-// (ms_tiles.hip) -- same K-th values bit for bit, a fraction of the tiles on clustered rows. Any order is correct with either value.
+// X_sorted / order (both or neither): the same rows in an order in which 32-row tiles are compact (sed_ms_sparse_prepare_f32's Xs
+// and order: sorted row i = row order[i]): the second sweep then runs on them and visits, per 128-row block, only the key tiles
+// whose cap can hold a value <= the block's thresholds (ms_tiles.hip) -- the same K-th values bit for bit (kth stays in X's row
+// order), a fraction of the tiles on clustered rows.
 extern "C" int sed_ms_kth_fused_f32(int B, int N, int d, int K, const float* X, float* kth, void* ws, size_t ws_bytes,
-                                    int* overflow, int sampling, int tile_coherent, hipStream_t stream) {
+                                    int* overflow, int sampling, const float* X_sorted, const int* order, hipStream_t stream) {
     if (B <= 0 || N <= 0 || K < 1 || K > N || !X || !kth || !ws || !overflow) return SED_EINVAL;
-    if ((sampling != 0 && sampling != 2 && sampling != 4) || (tile_coherent != 0 && tile_coherent != 1)) return SED_EINVAL;
+    if ((sampling != 0 && sampling != 2 && sampling != 4) || ((X_sorted != nullptr) != (order != nullptr))) return SED_EINVAL;
     const bool quarter = sampling != 2;
     if (d % 32 != 0 || d < 32 || d > 160 || K > sed_ms_kth_fused_max_k(N)) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_ms_kth_fused_workspace_bytes(B, N)) return SED_EINVAL;
     const KWs w = kcarve(ws, B, N);
-    void* tiles_ws = tile_coherent ? (void*)(((uintptr_t)((uint8_t*)ws + kth_base_bytes(B, N)) + 255) & ~(uintptr_t)255) : nullptr;
+    void* tiles_ws = (void*)(((uintptr_t)((uint8_t*)ws + kth_base_bytes(B, N)) + 255) & ~(uintptr_t)255);
     hipError_t e = hipMemsetAsync(overflow, 0, (size_t)B * sizeof(int), stream);
     if (e != hipSuccess) return (int)e;
     int rc = SED_OK;
     switch (d / 32) {
-        case 1: rc = launch_kth<1>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
-        case 2: rc = launch_kth<2>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
-        case 3: rc = launch_kth<3>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
-        case 4: rc = launch_kth<4>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;
-        default: rc = launch_kth<5>(B, X, w, N, K, overflow, quarter, tiles_ws, stream); break;     // d = 160 (HPNet-widened embedding): exact fp32 products
+        case 1: rc = launch_kth<1>(B, X, w, N, K, overflow, quarter, X_sorted, order, tiles_ws, stream); break;
+        case 2: rc = launch_kth<2>(B, X, w, N, K, overflow, quarter, X_sorted, order, tiles_ws, stream); break;
+        case 3: rc = launch_kth<3>(B, X, w, N, K, overflow, quarter, X_sorted, order, tiles_ws, stream); break;
+        case 4: rc = launch_kth<4>(B, X, w, N, K, overflow, quarter, X_sorted, order, tiles_ws, stream); break;
+        default: rc = launch_kth<5>(B, X, w, N, K, overflow, quarter, X_sorted, order, tiles_ws, stream); break;     // d = 160: exact fp32 products
     }
     if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
     ms_kth_finalize_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(w.lists, w.counts, K, rows, N, sed_sel_chunks(B, N), kth,
-                                                                           overflow);
+                                                                           overflow, X_sorted ? order : nullptr);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -52,7 +52,7 @@ SIGNATURES = {
     "sed_ms_iterate_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
     "sed_ms_kth_fused_max_k": (c_int, [c_int]),
     "sed_ms_kth_fused_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, c_int, c_int, P]),
+    "sed_ms_kth_fused_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, c_int, P, P, P]),
     "sed_ms_iterate_workspace_bytes": (c_size_t, [c_int, c_int, c_int, OPT]),
     "sed_ms_iterate_plan": (c_int, [c_int, c_int, c_int, OPT]),
     "sed_ms_iterate_kernel_name": (ctypes.c_char_p, [c_int, c_int, c_int, OPT]),

@@ -248,11 +248,9 @@ def ms_bandwidth(X, K, min_bw=0.003, prep=None):
         nbytes = lib.sed_ms_kth_fused_workspace_bytes(B, N)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=X.device)
         flag = torch.empty((B,), dtype=torch.int32, device=X.device)
-        kth_s = torch.empty_like(kth) if tiles else kth
-        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(prep["Xs"] if tiles else X), ptr(kth_s), ptr(ws), nbytes, ptr(flag),
-                                       int(KTH_SAMPLING), 1 if tiles else 0, stream()), "ms_kth_fused")
-        if tiles:                                            # back to the caller's row order: the mean below sums in that order
-            kth.scatter_(1, prep["order"].long(), kth_s)
+        check(lib.sed_ms_kth_fused_f32(B, N, D, K, ptr(X), ptr(kth), ptr(ws), nbytes, ptr(flag), int(KTH_SAMPLING),
+                                       ptr(prep["Xs"]) if tiles else None, ptr(prep["order"]) if tiles else None, stream()),
+              "ms_kth_fused")
         todo = torch.nonzero(flag.cpu()).squeeze(1)         # one small D->H copy
         FUSED_STATS["fused"] += B - todo.numel()
         FUSED_STATS["fallback"] += todo.numel()

@@ -59,6 +59,9 @@
 #ifndef F16S_PROFILE
 #define F16S_PROFILE 0           // 1: stats[5 .. 9] += per-wave clock ticks (s_memtime) spent in the stage barrier / in the whole sweep /
 #endif                           //    in first product + weights / in the second product / blocks timed (tools/sparse_ab.py prints them)
+#ifndef F16S_ENERGY_PROBE
+#define F16S_ENERGY_PROBE 0      // measurement only: 1 = every operand read from LDS issued TWICE, 2 = every stage copy issued TWICE,
+#endif                           // 4 = every MFMA issued twice (the second into a scratch accumulator); results unchanged
 #ifndef F16S_DELTA_V
 #define F16S_DELTA_V 0.005f
 #endif
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
 #pragma unroll
         for (int i = 0; i < (NPIECE + NW - 1) / NW; ++i) {
             const int pc = wave + NW * i;
-            if (pc < NPIECE) dma_piece(src + pc * 1024 + lane16, dst + pc * 1024);
+            if (pc < NPIECE) {
+                dma_piece(src + pc * 1024 + lane16, dst + pc * 1024);
+                if (F16S_ENERGY_PROBE & 2) dma_piece(src + pc * 1024 + lane16, dst + pc * 1024);
+            }
         }
     };
 
@@ -245,10 +251,18 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         if constexpr (t < KS) {
             fa[t & 3] = *(const h16x8*)(base + xoff + t * 32);
             fb[t & 3] = *(const h16x8*)(base + OFF_XL + xoff + t * 32);
+            if (F16S_ENERGY_PROBE & 1) {                 // the same reads again, kept alive by an empty asm
+                h16x8 e0 = *(const volatile h16x8*)(base + xoff + t * 32), e1 = *(const volatile h16x8*)(base + OFF_XL + xoff + t * 32);
+                asm volatile("" ::"v"(e0), "v"(e1));
+            }
         } else {
             constexpr int c = (t - KS) >> 1, j = (t - KS) & 1;
             fa[t & 3] = tr8(base, c, j);
             fb[t & 3] = tr8(base + OFF_XL, c, j);
+            if (F16S_ENERGY_PROBE & 1) {
+                h16x8 e0 = tr8(base, c, j), e1 = tr8(base + OFF_XL, c, j);
+                asm volatile("" ::"v"(e0), "v"(e1));
+            }
         }
     };
     // the stage barrier: every wave's share of the NEXT entry's copy has landed (the newest entry -- issued NBUF - 1 entries ahead
@@ -270,6 +284,9 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
     float rsum = 0.f;
     h16x8 ph[2], pl[2];
+    f32x16 edummy;                                        // (F16S_ENERGY_PROBE & 4 only)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) edummy[r] = 0.f;
 
     // Masks and list are reused while no query of the workgroup has turned by more than F16S_DELTA since they were made (the
     // thresholds carry that much extra slack): mean-shift moves rows in its first few iterations and then barely at all.
@@ -413,6 +430,11 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                     s = mfma16(fb[t & 3], qh[t], s);
                     s = mfma16(fa[t & 3], ql[t], s);
                     s = mfma16(fa[t & 3], qh[t], s);
+                    if (F16S_ENERGY_PROBE & 4) {
+                        edummy = mfma16(fb[t & 3], qh[t], edummy);
+                        edummy = mfma16(fa[t & 3], ql[t], edummy);
+                        edummy = mfma16(fa[t & 3], qh[t], edummy);
+                    }
                     ring_load(ic<t + 3>{}, buf);
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -490,6 +512,11 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
                     o[c] = mfma16(fb[t & 3], ph[jj], o[c]);
                     if (PL) o[c] = mfma16(fa[t & 3], pl[jj], o[c]);
                     o[c] = mfma16(fa[t & 3], ph[jj], o[c]);
+                    if (F16S_ENERGY_PROBE & 4) {
+                        edummy = mfma16(fb[t & 3], ph[jj], edummy);
+                        if (PL) edummy = mfma16(fa[t & 3], pl[jj], edummy);
+                        edummy = mfma16(fa[t & 3], ph[jj], edummy);
+                    }
                     if constexpr (t + 3 < NSTEP) ring_load(ic<t + 3>{}, buf);
                     else if (more) ring_load(ic<t + 3 - NSTEP>{}, nbuf);
                     __builtin_amdgcn_sched_barrier(0);
@@ -536,6 +563,7 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
             }
         }
         n2 += xor32(n2);
+        if (F16S_ENERGY_PROBE & 4) asm volatile("" ::"v"(edummy));
         const float nrm = sqrtf(n2);
         if (!PL && lowq != nullptr && nrm < 0.5f) lowq[cloud] = 1;       // weighted mean cancels: see ms_iterate_f16.hip
         if (it + 1 < iters) {   // new Q operand (exchange with the other lane half) and how far it is from where the masks were

@@ -291,6 +291,11 @@ MS_SPARSE_SKIP = -27.04
 # against 5.75; tools/sparse_ab.py, tools/hpnet_ms_ab.py); splitting a batch into a sparse and a dense launch costs more than the dense
 # kernel could win on the widest clouds (134 + 177 ms against 249 ms for all 64 sparse). Unstructured rows sit at 1.0.
 MS_SPARSE_MAX_NEAR = 0.6
+# d = 160 (the HPNet-widened embedding): the block-sparse kernel beats the key-chunked dense one up to a near fraction of ~0.5 per
+# cloud in isolation (5.3-8.1 ms against 8.2), loses 9-22 % beyond (9.0-10.2 ms) -- but a second, dense launch for the 11 of 64
+# bench clouds above 0.6 costs more than it wins (362 ms against 338 ms all-sparse, tools/hpnet_ms_ab.py): the threshold of the
+# wide embedding sits where only unstructured clouds fall to the dense kernel. Still a function of the cloud (and d) alone.
+MS_SPARSE_MAX_NEAR_WIDE = 0.95
 MS_SPARSE_STATS = {"sparse_clouds": 0, "dense_clouds": 0}
 MS_DENSE_GROUP = 16             # clouds per launch of the key-chunked dense kernel (where the planner's cost model puts the break-even)
 MS_SPARSE_FORM = 0              # item queueing of the block-sparse kernel: 0 = a cloud's items longest first, 1 = in row order (same bits)
@@ -421,7 +426,7 @@ def ms_iterate(X, bw, iters, prep=None):
     if MS_SPARSE != "off" and _MS_VARIANT == "auto" and D in (128, 160) and iters > 0 and 1024 <= N <= 16384:
         if MS_SPARSE == "on":
             return sparse_all()
-        sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < MS_SPARSE_MAX_NEAR).cpu()       # one small D->H copy
+        sparse = (ms_near_fraction(X, bw, MS_SPARSE_SKIP) < (MS_SPARSE_MAX_NEAR_WIDE if D == 160 else MS_SPARSE_MAX_NEAR)).cpu()   # one small D->H copy
         ns = int(sparse.sum())
         MS_SPARSE_STATS["sparse_clouds"] += ns
         MS_SPARSE_STATS["dense_clouds"] += B - ns

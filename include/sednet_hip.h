@@ -275,6 +275,17 @@ int sed_pointwise_split_weights_f32(int Cout, int Coutp, int K, const float* W, 
 int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
                                 const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,
                                 int flags, sed_stream_t stream);
+/* ---- the same GEMMs in the two-plane split-fp16 form of the selection kernels (split16.h: x 2^e = h + l, 3 fp16 MFMAs per
+ * product, dropped terms <= 3 2^-24 relative to |x|max |w|max of the row / channel, fp32 accumulation): half the matrix work of
+ * the bf16 form, but every input row needs a magnitude bound -- `rowmax` [B*N], the bit pattern of a float >= max_k |X[row][k]|,
+ * which sed_gn_apply_f32 (the producer of every such input in SEDNet.py:300-329) leaves behind. Coutp % 128 == 0.
+ * sed_pointwise_split16_weights_f32: W [Cout][K] -> planes h, l [Coutp][K] fp16 of W 2^e (e per output channel) + 2^-e [Coutp]. */
+size_t sed_pointwise_split16_weights_bytes(int Coutp, int K);
+int sed_pointwise_split16_weights_f32(int Cout, int Coutp, int K, const float* W, int ldw, void* wsplit,
+                                      sed_stream_t stream);
+int sed_pointwise_fwd_split16_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
+                                  const unsigned* rowmax, const float* bias, const float* cbias, float* Y, int ldy,
+                                  void* partials, void* colext, int flags, sed_stream_t stream);
 /* ---- training products (BASELINE configs[4]: bf16) ---------------------------------------------
  * sed_pointwise_fwd_bf16 / sed_edgeconv_fwd_train_bf16: the fp32 entry points' contracts with the products in bf16
  * (operands rounded to nearest even while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 / fp64 statistics;
@@ -297,10 +308,12 @@ int sed_gemm_f32(int M, int N, int K, const float* A, int lda, int transA, const
 int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps, const void* partials, float* stats,
                         sed_stream_t stream);
 /* out = scale * act(GN(Y)) + addend (stats NULL: no norm; act 0 none, 1 ReLU, 2 LeakyReLU(slope)).
- * src/SEDNet.py:303-326 (bn* + relu, and the w_pos_enc fusion adds at :322, :326) */
+ * src/SEDNet.py:303-326 (bn* + relu, and the w_pos_enc fusion adds at :322, :326)
+ * rowmax (optional, [B*N] unsigned, zeroed by the caller before the first call that fills a set of rows): atomically raised to
+ * the bit pattern of max_c |out[row][c]| -- several calls may fill column ranges of the same rows (C / 4 a power of two). */
 int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int ldy, const float* stats, const float* gamma,
                      const float* beta, int act, float slope, float scale, const float* addend, int lda, float* out,
-                     int ldo, sed_stream_t stream);
+                     int ldo, unsigned* rowmax, sed_stream_t stream);
 /* x4[b][o] = relu(GN(max/min over N)) from the column extrema of mlp1.   src/SEDNet.py:95-96 */
 int sed_colext_finalize_f32(int B, int N, int C, int G, const void* colext, const float* stats, const float* gamma,
                             const float* beta, float* out, sed_stream_t stream);

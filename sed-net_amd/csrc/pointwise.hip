@@ -213,20 +213,32 @@ __device__ __forceinline__ void split3(const f32x4& lo, const f32x4& hi4, bf16x8
     }
 }
 
-template <int TN>
+__device__ __forceinline__ void split2(const f32x4& lo, const f32x4& hi4, float scale, h16x8& h, h16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h16 a, b; split_pair(e < 4 ? lo[e & 3] : hi4[e & 3], scale, a, b); h[e] = a; l[e] = b; }
+}
+
+// H16: the two-plane split-fp16 form (split16.h) for inputs whose per-row magnitude bound the producer has already written
+// (`rowmax`, sed_gn_apply_f32): 3 fp16 MFMAs per 16 k instead of 6 bf16 ones, 2 weight planes instead of 3, a 5-instruction
+// split per activation instead of 9. The rows are scaled by 2^e (row bound in [2^13, 2^14)), the weights per output channel
+// (winv = 2^-e behind the planes); the epilogue unscales by the exact product of the two powers of two.
+template <int TN, bool H16>
 __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __restrict__ X, int ldx, int K,
-                                                                 const __bf16* __restrict__ Wp /* [3][Coutp][K] */,
+                                                                 const __bf16* __restrict__ Wp /* [3 | 2][Coutp][K] */,
                                                                  int Coutp, const float* __restrict__ bias,
                                                                  const float* __restrict__ cbias, float* __restrict__ Y,
                                                                  int ldy, int Cout, double* __restrict__ part,
-                                                                 float* __restrict__ colext, int N, int nblk, int flags) {
+                                                                 float* __restrict__ colext, int N, int nblk, int flags,
+                                                                 const unsigned* __restrict__ rowmax) {
     constexpr int BN = 32 * TN;
-    constexpr int LDH = 40;                                  // bf16 per LDS row (32 k + 8 pad = 80 B)
-    constexpr int NB = 3 * BN * 4 / 256;                     // 16-byte pieces of one weight stage per thread (6 / 3)
+    constexpr int LDH = 40;                                  // 16-bit values per LDS row (32 k + 8 pad = 80 B)
+    constexpr int NP = H16 ? 2 : 3;                          // weight planes
+    constexpr int NB = NP * BN * 4 / 256;                    // 16-byte pieces of one weight stage per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* Bs = (__bf16*)smem;                              // [2][3][BN][LDH]
-    double* red = (double*)(Bs + 2 * 3 * BN * LDH);          // [4][TN][2]
+    __bf16* Bs = (__bf16*)smem;                              // [2][NP][BN][LDH]
+    double* red = (double*)(Bs + 2 * NP * BN * LDH);         // [4][TN][2]
     float* ext = (float*)(red + 4 * TN * 2);                 // [4][BN][2]
+    float* ainv_s = ext + 4 * BN * 2;                        // [4][32] (H16): 2^-e of the waves' rows
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     // slot -> (point tile, channel block): slots L, L + 8, L + 16, ... run on XCD L % 8; consecutive slots of one XCD walk
@@ -263,9 +275,14 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int i = tid + 256 * u, pl = i / (BN * 4), row = (i / 4) % BN, seg = i & 3;
-            *(u32x4*)(Bs + ((buf * 3 + pl) * BN + row) * LDH + 8 * seg) = sb[u];
+            *(u32x4*)(Bs + ((buf * NP + pl) * BN + row) * LDH + 8 * seg) = sb[u];
         }
     };
+    float ascale = 1.f;
+    if (H16) {
+        ascale = split_row_scale(__uint_as_float(rowmax[(size_t)cloud * N + prow]));
+        if (hi == 0) ainv_s[wave * 32 + li] = 1.0f / ascale;      // visible after the first barrier below
+    }
 
     f32x16 acc[TN];
 #pragma unroll
@@ -275,26 +292,38 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
 
     auto step = [&](int ch, f32x4* xa, int cur) {
         bf16x8 a1[2], a2[2], a3[2];
+        h16x8 ah[2], al[2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) split3(xa[2 * s2], xa[2 * s2 + 1], a1[s2], a2[s2], a3[s2]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (H16) split2(xa[2 * s2], xa[2 * s2 + 1], ascale, ah[s2], al[s2]);
+            else split3(xa[2 * s2], xa[2 * s2 + 1], a1[s2], a2[s2], a3[s2]);
+        }
         if (ch + 2 < nchunk) load_a(ch + 2, xa);
         if (ch + 1 < nchunk) load_b(ch + 1);
-        const __bf16* b1p = Bs + ((cur * 3 + 0) * BN + li) * LDH + hi * 8;
+        const __bf16* b1p = Bs + ((cur * NP + 0) * BN + li) * LDH + hi * 8;
         const __bf16* b2p = b1p + BN * LDH;
         const __bf16* b3p = b2p + BN * LDH;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
-                const bf16x8 w1 = *(const bf16x8*)(b1p + 32 * t * LDH + 16 * s2);
-                const bf16x8 w2 = *(const bf16x8*)(b2p + 32 * t * LDH + 16 * s2);
-                const bf16x8 w3 = *(const bf16x8*)(b3p + 32 * t * LDH + 16 * s2);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w3, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s2], w1, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w2, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w2, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w1, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w1, acc[t], 0, 0, 0);
+                if (H16) {
+                    const h16x8 wh = *(const h16x8*)(b1p + 32 * t * LDH + 16 * s2);
+                    const h16x8 wl = *(const h16x8*)(b2p + 32 * t * LDH + 16 * s2);
+                    acc[t] = mfma16(al[s2], wh, acc[t]);
+                    acc[t] = mfma16(ah[s2], wl, acc[t]);
+                    acc[t] = mfma16(ah[s2], wh, acc[t]);
+                } else {
+                    const bf16x8 w1 = *(const bf16x8*)(b1p + 32 * t * LDH + 16 * s2);
+                    const bf16x8 w2 = *(const bf16x8*)(b2p + 32 * t * LDH + 16 * s2);
+                    const bf16x8 w3 = *(const bf16x8*)(b3p + 32 * t * LDH + 16 * s2);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w3, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s2], w1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2], w1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2], w1, acc[t], 0, 0, 0);
+                }
             }
         }
         if (ch + 1 < nchunk) store_b(cur ^ 1);
@@ -320,6 +349,12 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) vmask |= (pw + mfma_row(r, hi) < N ? 1u : 0u) << r;
     const bool full = pw + 32 <= N;
+    f32x4 ai4[4];                                            // (H16) 2^-e of this lane's 16 accumulator rows
+    const float* winv = (const float*)(Wp + (size_t)NP * plane);
+    if (H16) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ai4[g] = *(const f32x4*)&ainv_s[wave * 32 + 8 * g + 4 * hi];
+    }
     auto tiles = [&](auto relu_c, auto store_c, auto stats_c, auto ext_c, auto full_c) {
         constexpr bool RELU = decltype(relu_c)::value, STORE = decltype(store_c)::value, STATS = decltype(stats_c)::value,
                        EXT = decltype(ext_c)::value, FULL = decltype(full_c)::value;
@@ -331,9 +366,10 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
             float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
             const unsigned loff = (unsigned)(4 * hi * ldy + o);          // lane part of the address: row 4 hi, channel o
             const bool och = o < Cout;
+            const float wi = H16 ? winv[o] : 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[t][r] + add;
+                float v = H16 ? __fadd_rn(acc[t][r] * (ai4[r >> 2][r & 3] * wi), add) : acc[t][r] + add;
                 if (RELU) v = sed_vmax(v, 0.f);
                 const bool ok = FULL || ((vmask >> r) & 1u);
                 if (STORE && ok && och) {
@@ -418,7 +454,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int act, float slope,
                                                        float scale, const float* __restrict__ addend, int lda,
-                                                       float* __restrict__ out, int ldo, int N) {
+                                                       float* __restrict__ out, int ldo, int N,
+                                                       unsigned* __restrict__ rowmax) {
     const unsigned cloud = blockIdx.y;
     const unsigned c4n = (unsigned)C / 4;
     const unsigned rows_per_block = 256u / c4n > 0 ? 256u / c4n : 1u;      // c4n <= 256: whole rows per block pass
@@ -440,7 +477,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             b4[u] = fmaf(-a4[u], mean, be4[u]);
         }
     };
-    auto apply = [&](size_t row, unsigned cc) {
+    auto apply = [&](size_t row, unsigned cc) -> float {
         const f32x4 y = *(const f32x4*)(Y + row * ldy + cc);
         f32x4 ad = {0.f, 0.f, 0.f, 0.f};
         if (addend) ad = *(const f32x4*)(addend + row * lda + cc);
@@ -454,6 +491,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             o[u] = addend ? __fadd_rn(__fmul_rn(scale, v), ad[u]) : scale * v;   // (w * a) + x, SEDNet.py:322,326
         }
         *(f32x4*)(out + row * ldo + cc) = o;
+        return fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    };
+    // rowmax (optional): max |out| of every row, as float bits (non-negative floats order like their bit patterns), atomically
+    // merged so that several calls can fill column ranges of the same rows -- the row bound of sed_pointwise_fwd_split16_f32.
+    // The c4n lanes of a row that sit in one wave agree on their maximum first (power-of-two c4n only: the host checks).
+    auto merge_rowmax = [&](size_t row, float m, bool valid) {
+        const unsigned span = c4n < 64u ? c4n : 64u;
+        for (unsigned off = span >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, (int)off, 64));
+        if (valid && (threadIdx.x & (span - 1)) == 0) atomicMax(rowmax + row, __float_as_uint(m));
     };
     if (c4n <= 256u) {
         coeffs(c);
@@ -461,13 +507,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < GN_PT; ++k) {
             const unsigned p = p0 + k * rows_per_block;
-            if (p < (unsigned)N) apply((size_t)cloud * N + p, c);
+            float m = 0.f;
+            if (p < (unsigned)N) m = apply((size_t)cloud * N + p, c);
+            if (rowmax) merge_rowmax((size_t)cloud * N + p, m, p < (unsigned)N);
         }
     } else {                                                   // very wide layers: one row per block pass, channels strided
         for (int k = 0; k < GN_PT; ++k) {
             const unsigned p = blockIdx.x * GN_PT + k;
             if (p >= (unsigned)N) break;
-            for (unsigned cc = threadIdx.x * 4; cc < (unsigned)C; cc += 1024) { coeffs(cc); apply((size_t)cloud * N + p, cc); }
+            float m = 0.f;
+            for (unsigned cc = threadIdx.x * 4; cc < (unsigned)C; cc += 1024) { coeffs(cc); m = fmaxf(m, apply((size_t)cloud * N + p, cc)); }
+            if (rowmax) {
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                if ((threadIdx.x & 63) == 0) atomicMax(rowmax + (size_t)cloud * N + p, __float_as_uint(m));
+            }
         }
     }
 }
@@ -608,6 +661,26 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     Wp[2 * plane + i] = (__bf16)r2;
 }
 
+// one wave per output channel: the row's magnitude, its scale, the two planes
+__global__ __launch_bounds__(64) void split16_weights_kernel(const float* __restrict__ W, int ldwin, int Cout, int Coutp, int K,
+                                                             h16* __restrict__ Wp) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    const size_t plane = (size_t)Coutp * K;
+    float am = 0.f;
+    if (o < Cout)
+        for (int k = lane; k < K; k += 64) am = fmaxf(am, fabsf(W[(size_t)o * ldwin + k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    const float scale = split_row_scale(am);
+    for (int k = lane; k < K; k += 64) {
+        h16 a, b;
+        split_pair(o < Cout ? W[(size_t)o * ldwin + k] : 0.f, scale, a, b);
+        Wp[(size_t)o * K + k] = a;
+        Wp[plane + (size_t)o * K + k] = b;
+    }
+    if (lane == 0) ((float*)(Wp + 2 * plane))[o] = 1.0f / scale;
+}
+
 extern "C" size_t sed_pointwise_split_weights_bytes(int Coutp, int K) {
     return (size_t)Coutp * K * 3 * sizeof(__bf16);
 }
@@ -642,19 +715,56 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
         static std::atomic<unsigned long long> attr_set{0};      // devices whose limit has been raised (common.h)
         int attr_set_err = 0;
         if (sed_first_on_device(attr_set, &attr_set_err)) {
-            hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4>,
+            hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
             if (e != hipSuccess) return (int)e;
             sed_mark_device(attr_set);
         } else if (attr_set_err) return attr_set_err;
-        pointwise_split_kernel<4><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
+        pointwise_split_kernel<4, false><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
-            flags);
+            flags, nullptr);
     } else {
-        pointwise_split_kernel<2><<<dim3(nblk8 * (Coutp / 64), B), 256, smem(64, 2), stream>>>(
+        pointwise_split_kernel<2, false><<<dim3(nblk8 * (Coutp / 64), B), 256, smem(64, 2), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
-            flags);
+            flags, nullptr);
     }
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+extern "C" size_t sed_pointwise_split16_weights_bytes(int Coutp, int K) {
+    return (size_t)Coutp * K * 2 * sizeof(h16) + (size_t)Coutp * sizeof(float);
+}
+
+// W [Cout][K] -> the split-fp16 image of sed_pointwise_fwd_split16_f32: planes h, l [Coutp][K] fp16 of W 2^e (e per output
+// channel, split16.h) followed by winv [Coutp] = 2^-e. Rows >= Cout: zeros.
+extern "C" int sed_pointwise_split16_weights_f32(int Cout, int Coutp, int K, const float* W, int ldw, void* wsplit,
+                                                 hipStream_t stream) {
+    if (Cout <= 0 || Coutp < Cout || K <= 0 || K % 32 != 0 || !W || !wsplit || ldw < K) return SED_EINVAL;
+    split16_weights_kernel<<<Coutp, 64, 0, stream>>>(W, ldw, Cout, Coutp, K, (h16*)wsplit);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// sed_pointwise_fwd_split_f32 in the two-plane split-fp16 form. rowmax [B*N]: the bit pattern of a float >= max_k |X[row][k]|
+// for every row (what sed_gn_apply_f32 leaves in its `rowmax` argument; a bound that is too SMALL overflows fp16, one that is
+// 2^j too large costs j bits). Coutp % 128 == 0 only.
+extern "C" int sed_pointwise_fwd_split16_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
+                                             const void* wsplit, const unsigned* rowmax, const float* bias,
+                                             const float* cbias, float* Y, int ldy, void* partials, void* colext, int flags,
+                                             hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !X || !wsplit || !rowmax) return SED_EINVAL;
+    if (K % 32 != 0 || Coutp % 128 != 0 || ldx % 4 != 0 || ldx < K || Cout > Coutp) return SED_EUNSUPPORTED;
+    if ((flags & F_STORE) && (!Y || ldy < Cout)) return SED_EINVAL;
+    if ((flags & F_STATS) && !partials) return SED_EINVAL;
+    if ((flags & F_COLEXT) && !colext) return SED_EINVAL;
+    const int nblk = (N + 127) / 128;
+    const int nblk8 = (nblk + 7) / 8 * 8;
+    const size_t smem = (size_t)(2 * 2 * 128 * 40) * sizeof(h16) + 4 * 4 * 2 * sizeof(double) + 4 * 128 * 2 * sizeof(float) +
+                        4 * 32 * sizeof(float);
+    pointwise_split_kernel<4, true><<<dim3(nblk8 * (Coutp / 128), B), 256, smem, stream>>>(
+        X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk, flags,
+        rowmax);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -671,14 +781,15 @@ extern "C" int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count,
 // out = scale * act(GN(Y)) + addend ; stats NULL -> no normalisation; act 0 none / 1 ReLU / 2 LeakyReLU(slope)
 extern "C" int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int ldy, const float* stats,
                                 const float* gamma, const float* beta, int act, float slope, float scale,
-                                const float* addend, int lda, float* out, int ldo, hipStream_t stream) {
+                                const float* addend, int lda, float* out, int ldo, unsigned* rowmax, hipStream_t stream) {
     if (B <= 0 || N <= 0 || !Y || !out || C % 4 != 0 || ldy % 4 != 0 || ldo % 4 != 0) return SED_EINVAL;
+    if (rowmax && C <= 1024 && ((C / 4) & (C / 4 - 1)) != 0) return SED_EUNSUPPORTED;      // see merge_rowmax
     if (stats && (!gamma || !beta || G <= 0 || C % G != 0)) return SED_EINVAL;
     if (addend && lda % 4 != 0) return SED_EINVAL;
     const unsigned c4n = (unsigned)C / 4, rpb = c4n <= 256 ? 256 / c4n : 1;            // rows per block pass (see the kernel)
     const unsigned rows_per_block = rpb * GN_PT;
     gn_apply_kernel<<<dim3(((unsigned)N + rows_per_block - 1) / rows_per_block, B), 256, 0, stream>>>(
-        Y, ldy, C, G ? G : 1, stats, gamma, beta, act, slope, scale, addend, lda, out, ldo, N);
+        Y, ldy, C, G ? G : 1, stats, gamma, beta, act, slope, scale, addend, lda, out, ldo, N, rowmax);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

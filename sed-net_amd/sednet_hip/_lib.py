@@ -92,6 +92,9 @@ SIGNATURES = {
     "sed_pointwise_split_weights_bytes": (c_size_t, [c_int, c_int]),
     "sed_pointwise_split_weights_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P]),
     "sed_pointwise_fwd_split_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_pointwise_split16_weights_bytes": (c_size_t, [c_int, c_int]),
+    "sed_pointwise_split16_weights_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P]),
+    "sed_pointwise_fwd_split16_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, P, c_int, P, P, c_int, P]),
     "sed_pointwise_fwd_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
     "sed_edgeconv_fwd_train_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, P,
                                             P, P, P, c_size_t, P]),
@@ -99,7 +102,7 @@ SIGNATURES = {
     "sed_gemm_f32": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),
     "sed_gn_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_double, c_float, P, P, P]),
     "sed_gn_apply_f32": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_float, c_float, P, c_int,
-                                 P, c_int, P]),
+                                 P, c_int, P, P]),
     "sed_colext_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "sed_gemv_bias_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, P]),
     "sed_log_softmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, c_int, P]),

@@ -633,15 +633,23 @@ def edgeconv_bwd(x, C, idx, W1t, W2t, G, S, jsel, ak, need_dx, deterministic=Non
     return dW1t, dW2t, dx
 
 
-def gn_apply(Y, C, G, stats, gamma, beta, act, out, slope=0.0, scale=1.0, addend=None):
-    """out[..., :C] = scale * act(GN(Y[..., :C])) + addend; Y/out/addend are [B,N,ld*] views (row stride = ld)."""
+def gn_apply(Y, C, G, stats, gamma, beta, act, out, slope=0.0, scale=1.0, addend=None, rowmax=None):
+    """out[..., :C] = scale * act(GN(Y[..., :C])) + addend; Y/out/addend are [B,N,ld*] views (row stride = ld).
+    rowmax: optional row_bounds(B, N) tensor, raised to the rows' max |out| (the row bound of pointwise(..., rowmax=))."""
     B, N = Y.shape[0], Y.shape[1]
     check(lib.sed_gn_apply_f32(B, N, C, G, _vptr(Y), Y.stride(1), ptr(stats) if stats is not None else None,
                                ptr(gamma) if gamma is not None else None, ptr(beta) if beta is not None else None,
                                act, float(slope), float(scale), _vptr(addend) if addend is not None else None,
-                               addend.stride(1) if addend is not None else 0, _vptr(out), out.stride(1), stream()),
+                               addend.stride(1) if addend is not None else 0, _vptr(out), out.stride(1),
+                               ptr(rowmax) if rowmax is not None else None, stream()),
           "gn_apply")
     return out
+
+
+def row_bounds(B, N, device):
+    """zeroed per-row magnitude bounds (float bit patterns) for gn_apply(..., rowmax=) -> pointwise(..., rowmax=); None while
+    POINTWISE_SPLIT16 is off (both consumers then take their default forms)"""
+    return torch.zeros((B, N), dtype=torch.int32, device=device) if POINTWISE_SPLIT16 else None
 
 
 def _vptr(t):
@@ -651,6 +659,12 @@ def _vptr(t):
 
 
 POINTWISE_SPLIT = True  # inference GEMMs on the bf16 matrix pipe (3-way bf16 splits, fp32-equivalent); False: fp32 MFMA chains
+# ... and, where the producer left per-row bounds (rowmax), the two-plane split-fp16 form (half the MFMAs). OFF by default: measured
+# on the bench (round 4) it takes the nine wide layers of a forward from 7.35 to 6.0 ms only -- at K = 256 the kernel spends 70 % of
+# its VALU instructions in the prologue and the GroupNorm-statistics epilogue, the matrix pipe is 38 % (bf16 form) / 23 % (this form)
+# busy -- and its different rounding moves kNN-graph ties like any other 1e-7 perturbation of the features
+# (profiles/r04_forward_kernels.md); the default keeps the bits of round 3.
+POINTWISE_SPLIT16 = False
 TRAIN_BF16 = False      # training products in bf16 (operands rounded while staged, fp32 accumulate): BASELINE configs[4]
 
 
@@ -694,9 +708,22 @@ def _split_weights(Wt):
     return ws
 
 
-def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None):
+def _split16_weights(Wt):
+    """two-plane split-fp16 image (+ per-channel 2^-e) of Wt [K,Coutp]; cached like _split_weights"""
+    ws = getattr(Wt, "_sed_split16", None)
+    if ws is None:
+        K, Coutp = Wt.shape
+        W = Wt.t().contiguous()
+        ws = torch.empty((lib.sed_pointwise_split16_weights_bytes(Coutp, K),), dtype=torch.uint8, device=Wt.device)
+        check(lib.sed_pointwise_split16_weights_f32(Coutp, Coutp, K, ptr(W), K, ptr(ws), stream()), "split16_weights")
+        Wt._sed_split16 = ws
+    return ws
+
+
+def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None, rowmax=None):
     """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp]. bf16: products in bf16
-    (training). split (default POINTWISE_SPLIT): products by 3-way bf16 split emulation on the bf16 matrix pipe.
+    (training). split (default POINTWISE_SPLIT): products by 3-way bf16 split emulation on the bf16 matrix pipe; with rowmax (the
+    bounds gn_apply left for X's rows) and Coutp % 128 == 0: by the two-plane split-fp16 form.
     Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
     B, N = X.shape[0], X.shape[1]
     K, Coutp = Wt.shape
@@ -706,13 +733,16 @@ def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, 
     part = _bytes(lib.sed_pointwise_partials_bytes(B, N, Coutp), dev) if flags & F_STATS else None
     colext = _bytes(lib.sed_pointwise_colext_bytes(B, N, Coutp), dev) if flags & F_COLEXT else None
     split = POINTWISE_SPLIT if split is None else split
+    extra = ()
     if bf16:
         fwd, wptr = lib.sed_pointwise_fwd_bf16, ptr(Wt)
+    elif split and rowmax is not None and POINTWISE_SPLIT16 and Coutp % 128 == 0:
+        fwd, wptr, extra = lib.sed_pointwise_fwd_split16_f32, ptr(_split16_weights(Wt)), (ptr(rowmax),)
     elif split:
         fwd, wptr = lib.sed_pointwise_fwd_split_f32, ptr(_split_weights(Wt))
     else:
         fwd, wptr = lib.sed_pointwise_fwd_f32, ptr(Wt)
-    check(fwd(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), wptr,
+    check(fwd(B, N, K, Coutp, Cout, _vptr(X), X.stride(1), wptr, *extra,
               ptr(bias) if bias is not None else None, ptr(cbias) if cbias is not None else None,
               _vptr(out) if out is not None else None, out.stride(1) if out is not None else 0,
               ptr(part) if part is not None else None, ptr(colext) if colext is not None else None, flags, stream()),

@@ -91,19 +91,22 @@ class DGCNNEncoderGn(nn.Module):
             self._cache = c
         return self._cache
 
-    def _edge(self, key, x, C, idx, out_views):
+    def _edge(self, key, x, C, idx, out_views, rowmax=None):
+        """rowmax: row bounds raised by the LAST view's rows (the slice of `feats`)"""
         W1t, W2t, sgn, gamma, beta, G, eps = self._prepared()[key]
         ysel, stats = ops.edgeconv(x, C, idx, W1t, W2t, sgn, G, eps)
-        for o in out_views:
-            ops.gn_apply(ysel, ysel.shape[2], G, stats, gamma, beta, ops.ACT_LEAKY, o, slope=0.2)
+        for i, o in enumerate(out_views):
+            ops.gn_apply(ysel, ysel.shape[2], G, stats, gamma, beta, ops.ACT_LEAKY, o, slope=0.2,
+                         rowmax=rowmax if i == len(out_views) - 1 else None)
 
     def input_graph(self, x):
         """First-layer kNN graph: depends only on the input cloud (and k, W), not on the weights, so models that
         share k and normal_metric_W -- the type and instance models of the driver -- can share it."""
         return ops.knn_points_normals(x.detach().float().contiguous(), self.k, self.normal_metric_W)
 
-    def forward_point_major(self, x, idx1=None):
-        """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major). idx1: optional precomputed input_graph(x)."""
+    def forward_point_major(self, x, idx1=None, feats_bound=None):
+        """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major). idx1: optional precomputed input_graph(x).
+        feats_bound: optional ops.row_bounds(B, N) that receives max |feats| per row (for the split-fp16 layers on feats)."""
         if self.mode != 5 or self.input_channels != 6:
             raise NotImplementedError("the HIP path implements mode 5 with xyz+normal input (the SED-Net configuration)")
         B, _, N = x.shape
@@ -115,16 +118,17 @@ class DGCNNEncoderGn(nn.Module):
         x8[:, :, :6] = x.transpose(1, 2)
         idx = ops.knn_points_normals(x, k, self.normal_metric_W) if idx1 is None else idx1
         x1 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
-        self._edge("e1", x8, 6, idx, (x1, feats[:, :, 0:64]))
+        fb = feats_bound if feats_bound is not None else ops.row_bounds(B, N, dev)
+        self._edge("e1", x8, 6, idx, (x1, feats[:, :, 0:64]), rowmax=fb)
         idx = ops.knn_features(x1, k, 64)
         x2 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
-        self._edge("e2", x1, 64, idx, (x2, feats[:, :, 64:128]))
+        self._edge("e2", x1, 64, idx, (x2, feats[:, :, 64:128]), rowmax=fb)
         idx = ops.knn_features(x2, k, 64)
-        self._edge("e3", x2, 64, idx, (feats[:, :, 128:256],))
+        self._edge("e3", x2, 64, idx, (feats[:, :, 128:256],), rowmax=fb)
         Wt, b = self._prepared()["mlp1"]
         gamma, beta = self._prepared()["bnmlp1"]
         _, stats, colext = ops.pointwise(feats, Wt, 1024, bias=b, flags=ops.F_STATS | ops.F_COLEXT, G=8,
-                                         eps=self.bnmlp1.eps)
+                                         eps=self.bnmlp1.eps, rowmax=fb)
         x4 = ops.colext_finalize(colext, B, N, 1024, 8, stats, gamma, beta)
         return x4, feats
 
@@ -243,13 +247,15 @@ class SEDNet(nn.Module):
         return self._cache
 
     def _conv_gn_relu(self, X, conv_key, bn_key, G, C, eps, act=ops.ACT_RELU, scale=1.0, addend=None, cbias=None,
-                      Wt=None, bias=None):
+                      Wt=None, bias=None, x_bound=None, y_bound=None):
+        """x_bound: the row bounds of X (-> the split-fp16 product); y_bound: row bounds to raise with the result's rows"""
         c = self._prepared()
         if Wt is None:
             Wt, bias = c[conv_key]
-        Y, stats, _ = ops.pointwise(X, Wt, C, bias=bias, cbias=cbias, flags=ops.F_STORE | ops.F_STATS, G=G, eps=eps)
+        Y, stats, _ = ops.pointwise(X, Wt, C, bias=bias, cbias=cbias, flags=ops.F_STORE | ops.F_STATS, G=G, eps=eps,
+                                    rowmax=x_bound)
         gamma, beta = c[bn_key]
-        return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend)
+        return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend, rowmax=y_bound)
 
     def forward_point_major(self, points, idx1=None):
         """points [B,6,N] -> (embedding [B,N,emb], log_prob [B,N,P], edges [B,N,2]) point-major device tensors
@@ -263,28 +269,33 @@ class SEDNet(nn.Module):
             c = self._prepared()
             B, _, N = points.shape
             dev = points.device
-            x4, feats = self.encoder.forward_point_major(points, idx1)
+            # per-row magnitude bounds of the GroupNorm outputs: what lets the next layer run in the two-plane split-fp16 form
+            bnd = [ops.row_bounds(B, N, dev) for _ in range(5)]
+            x4, feats = self.encoder.forward_point_major(points, idx1, feats_bound=bnd[0])
             # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
             cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
-            a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"])
-            x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps)                      # :304
-            x_type = self._conv_gn_relu(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps)  # :311
+            a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"],
+                                    x_bound=bnd[0], y_bound=bnd[1])
+            x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps, x_bound=bnd[1], y_bound=bnd[2])   # :304
+            x_type = self._conv_gn_relu(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps,
+                                        x_bound=bnd[2], y_bound=bnd[3])                               # :311
             P = self.num_primitives
             te = torch.zeros((B, N, 32), dtype=torch.float32, device=dev)       # cat(type_logit, edges), K padded
             Wt, b = c["prim2"]
             ops.pointwise(x_type, Wt, P, bias=b, out=te[:, :, 0:P])                                  # :312
             log_prob = ops.log_softmax_rows(te, P)                                                      # :313
-            e1 = self._conv_gn_relu(x_type, "edge0", "edge1", 4, 128, self.edge_module[1].eps, act=ops.ACT_NONE)
+            e1 = self._conv_gn_relu(x_type, "edge0", "edge1", 4, 128, self.edge_module[1].eps, act=ops.ACT_NONE,
+                                    x_bound=bnd[3])
             Wt, b = c["edge2"]
             ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2])                                  # :316-317
-            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps)          # :320
+            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2])   # :320
             x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
-                                   scale=self.w_pos_enc, addend=xs)                                    # :322
+                                   scale=self.w_pos_enc, addend=xs, x_bound=bnd[3])                    # :322
             Wt, b = c["penc"]
             pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)             # :326
-            x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x)
+            x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x, rowmax=bnd[4])
             Wt, b = c["seg2"]
-            emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b)                                   # :329
+            emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b, rowmax=bnd[4])                    # :329
         return emb, log_prob, te[:, :, P:P + 2]
 
     def forward_point_major_train(self, points, idx1=None):

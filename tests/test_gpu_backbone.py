@@ -197,3 +197,76 @@ def test_split_bf16_gemm_equals_fp32_gemm(T, K, Cout, flags_relu):
     assert es < 4e-7 and ef < 2e-6, (es, ef)
     if ss is not None:
         np.testing.assert_allclose(ss.cpu().numpy(), sf.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("K,Cout,flags_relu", [(256, 1024, False), (512, 256, True), (256, 128, False)])
+def test_split_fp16_gemm_with_row_bounds_equals_fp32_gemm(T, K, Cout, flags_relu, monkeypatch):
+    """pointwise_split_kernel<4, true>: two fp16 planes per operand, rows scaled by the bound the producer left (here: the exact
+    row maximum, and for some rows a bound 8x too large), channels by their own maximum; 3 MFMAs per product. Same yardstick as
+    the bf16 form: closer to float64 than the fp32 chain on the dot product's natural error scale."""
+    from sednet_hip import ops
+    monkeypatch.setattr(ops, "POINTWISE_SPLIT16", True)
+    g = T.Generator().manual_seed(3 * K + Cout)
+    B, N = 2, 1000
+    X = T.randn(B, N, K, generator=g).clamp_min(0) + 0.05 * T.randn(B, N, K, generator=g)       # post-GroupNorm-ReLU-like rows
+    X[:, ::7] *= 1.0e4                                           # large rows: every row has its own scale
+    X[:, 1::7] *= 1.0e-5
+    X[:, :, 32:64] *= 1.0e-2                                     # a small chunk
+    X[0, 5] = 0.0                                                # an all-zero row
+    X = X.cuda()
+    Wt = (T.randn(K, Cout, generator=g) / K ** 0.5)
+    Wt[:, 3] *= 1.0e3
+    Wt[:, 7] = 0.0
+    Wt = Wt.cuda()
+    bias = T.randn(Cout, generator=g).cuda()
+    bound = X.abs().amax(-1)
+    bound[:, ::3] *= 8.0
+    rowmax = bound.contiguous().view(T.int32)
+    fl = ops.F_STORE | ops.F_STATS | (ops.F_RELU if flags_relu else 0)
+    Ys, ss, _ = ops.pointwise(X, Wt, Cout, bias=bias, flags=fl, G=2, rowmax=rowmax)
+    Yf, sf, _ = ops.pointwise(X, Wt, Cout, bias=bias, flags=fl, G=2, split=False)
+    Yb, _, _ = ops.pointwise(X, Wt, Cout, bias=bias, flags=fl, G=2)
+    assert not T.equal(Ys, Yb)                                   # the fp16 form did run
+    ref = X.double() @ Wt.double() + bias.double()
+    if flags_relu:
+        ref = ref.clamp_min(0)
+    scale = (X.double().abs() @ Wt.double().abs() + bias.double().abs()).clamp_min(1e-30)
+    es = ((Ys.double() - ref).abs() / scale).max().item()
+    ef = ((Yf.double() - ref).abs() / scale).max().item()
+    assert es < 4e-7 and ef < 2e-6, (es, ef)
+    np.testing.assert_allclose(ss.cpu().numpy(), sf.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_gn_apply_leaves_row_bounds(T, monkeypatch):
+    """sed_gn_apply_f32's rowmax: max |out| per row, merged over calls that fill column ranges of the same rows."""
+    from sednet_hip import ops
+    monkeypatch.setattr(ops, "POINTWISE_SPLIT16", True)
+    g = T.Generator().manual_seed(77)
+    B, N = 2, 777
+    out = T.zeros(B, N, 256).cuda()
+    rb = ops.row_bounds(B, N, out.device)
+    for c0, C in ((0, 64), (64, 64), (128, 128)):
+        Y = (T.randn(B, N, C, generator=g) * 10.0 ** T.randint(-3, 3, (B, N, 1), generator=g)).cuda()
+        stats = T.stack([T.randn(B, 2, generator=g), T.rand(B, 2, generator=g) + 0.5], -1).cuda().contiguous()
+        gamma, beta = T.randn(C, generator=g).cuda(), T.randn(C, generator=g).cuda()
+        ops.gn_apply(Y, C, 2, stats, gamma, beta, ops.ACT_LEAKY, out[:, :, c0:c0 + C], slope=0.2, rowmax=rb)
+    assert T.equal(rb.view(T.float32), out.abs().amax(-1))
+    wide = T.randn(B, N, 512, generator=g).cuda()
+    rb2 = ops.row_bounds(B, N, out.device)
+    o2 = ops.gn_apply(wide, 512, 0, None, None, None, ops.ACT_RELU, T.empty_like(wide), scale=0.5, addend=wide, rowmax=rb2)
+    assert T.equal(rb2.view(T.float32), o2.abs().amax(-1))
+
+
+def test_split_fp16_forward_is_an_fp32_equivalent_forward(T, monkeypatch):
+    """The opt-in split-fp16 route through the whole network (row bounds from gn_apply -> pointwise): embeddings and log-probs
+    equal the default route's to fp32 rounding on a cloud where no kNN tie flips."""
+    from sednet_hip import ops, synth
+    m = build(T, 20, "inst")
+    x = T.from_numpy(synth.batch_clouds(2, 2048, seed0=41)[0]).cuda()
+    e0, l0, _ = m.forward_point_major(x)
+    monkeypatch.setattr(ops, "POINTWISE_SPLIT16", True)
+    e1, l1, _ = m.forward_point_major(x)
+    assert not T.equal(e0, e1)
+    err = (e1 - e0).abs().amax(-1) / e0.abs().amax(-1)
+    assert float(err.median()) < 2e-6 and float(err.quantile(0.99)) < 1e-4, (float(err.median()), float(err.max()))
+    assert float((l1 - l0).abs().median()) < 2e-6

@@ -461,7 +461,7 @@ def main():
         # ---- round 1 / 2's workload: closed-form weights, one-blob embedding -> every cloud on the dense kernel
         if world == 1:
             mc = build_models(args.k, dev, "closed-form")
-            pipe_c = SegmentationPipeline(mc[0], mc[1], quantile=0.015, iterations=args.iterations)
+            pipe_c = SegmentationPipeline(mc[0], mc[1], quantile=0.015, iterations=args.iterations, hpnet=False)
             un = {}
             for digits in (2, 1):
                 ops.ms_set_weight_digits(digits)
@@ -506,7 +506,7 @@ def main():
         if world == 1 and args.k != 64 and not args.no_k64:
             # also report the reference's default neighbourhood size k = 64 (same clouds, same path)
             m64 = build_models(64, dev, "trained")
-            pipe64 = SegmentationPipeline(m64[0], m64[1], quantile=0.015, iterations=args.iterations)
+            pipe64 = SegmentationPipeline(m64[0], m64[1], quantile=0.015, iterations=args.iterations, hpnet=False)
             xb = x[:B]
             pipe64(xb)
             torch.cuda.synchronize()

@@ -194,7 +194,7 @@ def test_config2_batch64_full_path_with_planted_segments(T):
     B, N, k = 64, 10000, 20
     x, labels, types = synth.batch_clouds(B, N, seed0=1234)
     X, planted = synth.planted_embedding(labels, d=128, sigma=0.01, seed=3, guard_clouds=(17,))
-    pipe = SegmentationPipeline(build(T, k, 0), build(T, k, 1), quantile=0.015, iterations=50)
+    pipe = SegmentationPipeline(build(T, k, 0), build(T, k, 1), quantile=0.015, iterations=50, hpnet=False)
     out = pipe(T.from_numpy(x).cuda(), embedding=X, types=T.from_numpy(types.astype(np.int32)).cuda())
     got = out["labels"].cpu().numpy()
     planted = planted.cpu().numpy()
@@ -229,7 +229,7 @@ def test_config2_batch64_trained_network_no_injection(T, golden, capsys):
     g, unstable = golden("f_10k"), golden("f_10k_unstable")
     B, N, k = 64, 10000, 20
     x, labels, types = synth.batch_clouds(B, N, seed0=1234)
-    pipe = SegmentationPipeline(build(T, k, "type"), build(T, k, "inst"), quantile=0.015, iterations=50)
+    pipe = SegmentationPipeline(build(T, k, "type"), build(T, k, "inst"), quantile=0.015, iterations=50, hpnet=False)
     out = pipe(T.from_numpy(x).cuda())
     got, ty = out["labels"].cpu().numpy(), out["types"].cpu().numpy()
     ncl = np.asarray(out["n_labels"])

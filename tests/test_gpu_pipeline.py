@@ -29,7 +29,7 @@ def test_pipeline_matches_oracle_stagewise(T):
     from src.segment_utils import seg_iou
     B, N, k = 2, 1500, 20
     x, _, _ = synth.batch_clouds(B, N, seed0=900)
-    pipe = SegmentationPipeline(build(T, k, 0), build(T, k, 1), quantile=0.015, iterations=20)
+    pipe = SegmentationPipeline(build(T, k, 0), build(T, k, 1), quantile=0.015, iterations=20, hpnet=False)
     out = pipe(T.from_numpy(x).cuda())
     labels = out["labels"].cpu().numpy()
     types = out["types"].cpu().numpy()
@@ -150,7 +150,7 @@ def test_deferred_knn_overflow_flags(T):
     import bench
     m_type, m_inst = bench.build_models(20, T.device("cuda"))
     x = T.from_numpy(synth.batch_clouds(2, 4096, seed0=77)[0]).cuda()
-    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=10)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=10, hpnet=False)
     before = dict(ops.FUSED_STATS)
     pipe(x)
     assert ops.FUSED_STATS["fused"] >= before["fused"] + 5 and ops.FUSED_STATS["fallback"] == before["fallback"]
@@ -177,7 +177,7 @@ def test_pipeline_outputs_are_bit_reproducible(T):
     x_np, l_np, t_np = synth.batch_clouds(B, 10000, seed0=1234)
     x = T.from_numpy(x_np).cuda()
     m_type, m_inst = bench.build_models(20, T.device("cuda"))
-    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50, hpnet=False)
     Xp, _ = synth.planted_embedding(l_np, d=128, sigma=0.01, seed=3, guard_clouds=(B - 1,))
     tp = T.from_numpy(t_np.astype(np.int32)).cuda()
     for kw in ({}, {"embedding": Xp, "types": tp}):
@@ -202,7 +202,7 @@ def test_two_stream_forwards_give_the_same_outputs(T):
     import bench
     x = T.from_numpy(synth.batch_clouds(2, 10000, seed0=4321)[0]).cuda()
     m_type, m_inst = bench.build_models(20, T.device("cuda"))
-    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=20)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=20, hpnet=False)
     assert pipe.TWO_STREAM_MAX_CLOUDS >= 2
     try:
         pipe.TWO_STREAM_MAX_CLOUDS = 0
@@ -230,7 +230,7 @@ def test_graph_forwards_follow_weight_updates(T):
     import bench
     x = T.from_numpy(synth.batch_clouds(1, 4096, seed0=99)[0]).cuda()
     m_type, m_inst = bench.build_models(20, T.device("cuda"))
-    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=5)
+    pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=5, hpnet=False)
     with warnings.catch_warnings():
         warnings.simplefilter("error")                          # a failed capture would only warn and fall back: make it fail
         a = pipe(x)

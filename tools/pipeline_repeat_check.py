@@ -12,7 +12,7 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 x_np, l_np, t_np = synth.batch_clouds(B, 10000, seed0=1234)
 x = torch.from_numpy(x_np).cuda()
 m_type, m_inst = bench.build_models(20, torch.device("cuda"))
-pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50)
+pipe = SegmentationPipeline(m_type, m_inst, quantile=0.015, iterations=50, hpnet=False)
 Xp, _ = synth.planted_embedding(l_np, d=128, sigma=0.01, seed=3, guard_clouds=(B - 1,))
 tp = torch.from_numpy(t_np.astype(np.int32)).cuda()
 for name, kw in (("network embedding", {}), ("planted segments", {"embedding": Xp, "types": tp})):

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
 #if F16S_PROFILE
     unsigned long long t_bar = 0, t_sweep = 0, t_fp = 0, t_sp = 0;
 #define F16S_NOW() __builtin_readcyclecounter()
+    const unsigned long long t_wg0 = wall_clock64();
 #endif
     for (;;) {
     __syncthreads();                                      // every wave is done with the previous item (shared tables, item_sh)
@@ -626,6 +627,12 @@ __global__ __launch_bounds__(64 * F16S_NW, 2) void ms_sparse_f16_kernel(
         atomicAdd(stats + 6, t_sweep);
         atomicAdd(stats + 7, t_fp);
         atomicAdd(stats + 8, t_sp);
+        if (tid == 0) {                                   // [9] / [10]: earliest / latest workgroup exit on the 100 MHz wall clock (the
+            const unsigned long long now = wall_clock64();          // launch's tail); the caller presets [9] to ~0
+            atomicMin(stats + 9, now);
+            atomicMax(stats + 10, now);
+            atomicMin(stats + 11, t_wg0);
+        }
 #endif
     }
 }

@@ -398,6 +398,23 @@ int sed_pair_entropy_split_f32(int M, int K, const float* u, int ldu, void* spli
 int sed_pair_entropy_mfma_f32(int M, const void* split, int mode, float alpha, const float* alpha_dev, double* partials,
                               sed_stream_t stream);
 
+/* ---- evaluation of a batch on the device ------------------------------------------------------------
+ * What generate_predictions_aug.py:389-441 logs per cloud -- src/segment_utils.py:194-242 (SIOU_matched_segments_usecd) with
+ * :424-494, :509-517, :609-627 and fitting_utils.py:362-376 (match: lapsolver.solve_dense on the host) -- for hard labels:
+ * K x K overlap tables, cost 1 - relaxed IoU (the reference's fp32 operation order), the assignment by one wave per cloud
+ * (Hungarian algorithm, fp64 duals, K <= 64; exact optimum, ties between equal-cost optima -> lowest column), chamfer distance of
+ * every matched pair, means in fp64.
+ * pred_labels / gt_labels in [0, K) (K = 50: to_one_hot's width), pred_types / gt_types: per-point type ids (folded here:
+ * {0,6,7} -> 9, 8 -> 2), points [B][N][3]; idx_by_pred / idx_by_gt [B][N]: the cloud's point indices sorted STABLY by predicted /
+ * true label. metrics [B][4] = (segment IoU, type IoU, chamfer recall, pairs used; NaN where the reference's np.mean([]) is),
+ * col_of_row [B][K] the matching, pairs [B][K][2] (optional) = (true type, predicted type) per row or (-1, -1),
+ * bad: set to 1 if a label or type is out of range (the reference's one-hot scatter would raise). */
+size_t sed_segment_metrics_workspace_bytes(int B, int K);
+int sed_segment_metrics_f32(int B, int N, int K, const int* pred_labels, const int* gt_labels, const int* pred_types,
+                            const int* gt_types, const float* points, const int* idx_by_pred, const int* idx_by_gt,
+                            double* metrics, int* col_of_row, int* pairs, int* bad, void* workspace, size_t workspace_bytes,
+                            sed_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

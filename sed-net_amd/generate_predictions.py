@@ -31,7 +31,7 @@ from read_config import Config                      # noqa: E402
 from sednet_hip import ops, synth                    # noqa: E402
 from src.mean_shift import MeanShift                 # noqa: E402
 from src.SEDNet import SEDNet                        # noqa: E402
-from src.segment_utils import SIOU_matched_segments_usecd, seg_iou                # noqa: E402
+from src.segment_utils import SIOU_matched_segments_usecd, SIOU_matched_segments_usecd_batch, seg_iou   # noqa: E402
 
 DROP_OUT_NUM = 2000                                  # generate_predictions_aug.py:65
 ITERATIONS, QUANTILE = 50, 0.015                     # :188-189
@@ -123,6 +123,9 @@ def main(argv=None):
                          "use_hpnet = True at :58; its lobpcg start is random, so labels match a reference run statistically)")
     ap.add_argument("--hpnet", dest="hpnet", action="store_true", help="(default) HPNet spectral re-weighting on")
     ap.set_defaults(hpnet=True)
+    ap.add_argument("--host-metrics", action="store_true",
+                    help="evaluate cloud by cloud with the reference-surface function (Hungarian matching on the host) instead of "
+                         "the batched device evaluation (same numbers)")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="closed-form synthetic weights instead of the checkpoints named by the config (tests, benchmarks)")
     ap.add_argument("--ms-weight-digits", type=int, choices=[1, 2], default=2,
@@ -161,12 +164,27 @@ def main(argv=None):
             labels, bw, n_labels, passes = ms.guard_mean_shift_batch(X, QUANTILE, ITERATIONS)   # :382
             edge_prob = torch.softmax(edges, dim=2)                                  # :435
         labels_h, types_h, edge_h = labels.cpu().numpy(), pred_types.cpu().numpy(), edge_prob.cpu().numpy()
-        for i in range(x.shape[0]):
+        nb = x.shape[0]
+        have = [labels_all is not None and labels_all[b0 + i] is not None and types_all is not None and types_all[b0 + i] is not None
+                for i in range(nb)]
+        batch_metrics = None
+        if all(have) and not args.host_metrics:
+            # :389-410 for the whole batch on the device: tables, Hungarian assignment (one wave per cloud), pair chamfer, means
+            gt_d = torch.as_tensor(np.stack([np.asarray(labels_all[b0 + i]) for i in range(nb)]).astype(np.int32), device=device)
+            gtt_d = torch.as_tensor(np.stack([np.asarray(types_all[b0 + i]) for i in range(nb)]).astype(np.int32), device=device)
+            s_d, p_d, _, _, r_d = SIOU_matched_segments_usecd_batch(gt_d, labels, pred_types, gtt_d,
+                                                                    x[:, 0:3].transpose(1, 2).contiguous())
+            batch_metrics = torch.stack([s_d, p_d, r_d], 1).cpu().numpy()                # one D->H copy per batch
+        for i in range(nb):
             cid = ids[b0 + i]
             msg = f"ID:{cid} | clusters {n_labels[i]} (passes {passes[i]})"
             gt = labels_all[b0 + i] if labels_all is not None else None
             gt_types = types_all[b0 + i] if types_all is not None else None         # per cloud: an .npz may lack either
-            if gt is not None and gt_types is not None:                                                  # :389-410
+            if batch_metrics is not None:
+                s, p, rec = (float(v) for v in batch_metrics[i])
+                s_ious.append(s); p_ious.append(p); recalls.append(rec)
+                msg += f" inst_iou: {s:.4f} type_iou: {p:.4f} inst_recall: {rec:.4f}"
+            elif gt is not None and gt_types is not None:                                                # :389-410, per cloud on the host
                 w = torch.nn.functional.one_hot(labels[i].long(), 50).float()
                 s, p, _, _, rec = SIOU_matched_segments_usecd(np.asarray(gt).astype(np.int64), labels_h[i].astype(np.int64),
                                                               types_h[i].astype(np.int64).copy(),

@@ -854,6 +854,33 @@ def segment_type_vote(labels, types, S, C=6):
     return seg_type, seg_count
 
 
+def segment_metrics(pred_labels, gt_labels, pred_types, gt_types, points, K=50):
+    """The evaluation of generate_predictions_aug.py:389-441 for a batch, on the device (seg_metrics.hip): labels / per-point types
+    [B,N] integer device tensors (labels in [0, K)), points [B,N,3] -> (metrics [B,4] f64 = segment IoU, type IoU, chamfer recall,
+    pairs used; matching col_of_row [B,K] i32; pairs [B,K,2] i32 (true type, predicted type) or -1). One host sync (the range flag)."""
+    B, N = pred_labels.shape
+    dev = pred_labels.device
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    pl, gl, pt, gtt = i32(pred_labels), i32(gt_labels), i32(pred_types), i32(gt_types)
+    pts = points.float().contiguous()
+    assert pts.shape == (B, N, 3)
+    idx_p = torch.sort(pl, dim=1, stable=True).indices.to(torch.int32).contiguous()
+    idx_g = torch.sort(gl, dim=1, stable=True).indices.to(torch.int32).contiguous()
+    metrics = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    col = torch.empty((B, K), dtype=torch.int32, device=dev)
+    pairs = torch.empty((B, K, 2), dtype=torch.int32, device=dev)
+    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nws = lib.sed_segment_metrics_workspace_bytes(B, K)
+    if nws == 0:
+        raise ValueError(f"segment_metrics: K = {K} is outside 1 .. 64")
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    check(lib.sed_segment_metrics_f32(B, N, K, ptr(pl), ptr(gl), ptr(pt), ptr(gtt), ptr(pts), ptr(idx_p), ptr(idx_g), ptr(metrics),
+                                      ptr(col), ptr(pairs), ptr(bad), ptr(ws), nws, stream()), "segment_metrics")
+    if int(bad.item()):
+        raise ValueError(f"segment_metrics: a label is outside [0, {K}) or a type id outside [0, 10) (the reference's one-hot raises)")
+    return metrics, col, pairs
+
+
 # ---------------------------------------------------------------------------------------------------
 # HPNet entropy weights
 # ---------------------------------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 """Segment helpers on the hot path -- /root/reference/src/segment_utils.py:536-545 (to_one_hot) plus the
-seg-IoU used to check "seg-IoU within 1e-3 of the reference" (host-side, tiny;
-Hungarian matching via scipy instead of lapsolver). The remaining metrics of that file are out of scope."""
+seg-IoU used to check "seg-IoU within 1e-3 of the reference"  and the evaluation the script logs.
+The per-cloud functions keep the reference's signatures (Hungarian matching on the host via scipy instead of lapsolver);
+SIOU_matched_segments_usecd_batch is the same evaluation for a whole batch on the device (sednet_hip.ops.segment_metrics:
+one wave per cloud solves the assignment). The remaining metrics of that file are out of scope."""
 import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -147,3 +149,13 @@ def SIOU_matched_segments_usecd(target, pred_labels, primitives_pred, primitives
         matching, np.expand_dims(pred_labels, 0), np.expand_dims(target, 0), np.expand_dims(prim_pred, 0),
         np.expand_dims(primitives, 0), points)
     return s_iou, p_iou, matching, pairs, recall
+
+
+def SIOU_matched_segments_usecd_batch(target, pred_labels, primitives_pred, primitives, points, K=50):
+    """segment_utils.py:194-242 for a batch, hard labels, on the device: target / pred_labels / primitives_pred / primitives
+    [B,N] integer device tensors (type ids unfolded: the kernels fold {0,6,7} -> 9, 8 -> 2 themselves and leave the inputs alone),
+    points [B,N,3]. -> (segment IoU [B], type IoU [B], matching [B,K] (column of every row), type pairs [B,K,2], chamfer recall [B])
+    as device tensors; what generate_predictions_aug.py:441 logs is the mean of each over the clouds."""
+    from sednet_hip import ops
+    m, col, pairs = ops.segment_metrics(pred_labels, target, primitives_pred, primitives, points, K)
+    return m[:, 0], m[:, 1], col, pairs, m[:, 2]

@@ -61,6 +61,29 @@ def test_driver_end_to_end(tmp_path):
         np.testing.assert_allclose(edge.sum(1), 1.0, atol=2e-4)
 
 
+def test_driver_device_metrics_equal_host_metrics(tmp_path, caplog):
+    """The numbers the script logs (generate_predictions_aug.py:389-441): evaluated for the batch on the device (default) and cloud
+    by cloud through the reference-surface function with the host assignment (--host-metrics): the same lines."""
+    import logging
+    import re
+    import generate_predictions as gp
+    cfg = tmp_path / "config.yml"
+    cfg.write_text(CFG)
+    lines = {}
+    for flag in ((), ("--host-metrics",)):
+        caplog.clear()
+        with caplog.at_level(logging.INFO):
+            rc = gp.main([str(cfg), "NoSave", "no_multi_vote", "no_fold5drop", "--synthetic", "5", "--points", "2000", "--batch", "3",
+                          "--no-hpnet", "--synthetic-weights", *flag])
+        assert rc == 0
+        lines[flag] = [m for m in (r.getMessage() for r in caplog.records) if "inst_iou" in m]
+    dev, host = lines[()], lines[("--host-metrics",)]
+    assert len(dev) == len(host) == 6 and "type_iou" in dev[0] and "inst_recall" in dev[0]
+    num = lambda l: [float(v) for v in re.findall(r"(?:iou|recall): (?:\[)?([0-9.eE+-]+|nan)", l)]
+    for a_, b_ in zip(dev, host):
+        np.testing.assert_allclose(num(a_), num(b_), rtol=1e-9, atol=1e-4)      # per-cloud lines print 4 decimals
+
+
 def test_driver_checkpoint_and_input_contract(tmp_path):
     """A missing checkpoint is an error like in the reference (torch.load raises there, generate_predictions_aug.py:
     191-198) -- no silent synthetic weights; .npz inputs may carry labels without primitives (seg-IoU only), both, or

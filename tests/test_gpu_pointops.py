@@ -128,3 +128,90 @@ def test_differentiable_operators_have_gradients(T):
     it = (f2[bi[:, :, None], :, idx3.long()] * w3[..., None]).sum(2).permute(0, 2, 1)
     ((ga * cot1).sum() + (gr * cot2).sum() + (it * cot3).sum()).backward()
     np.testing.assert_allclose(got.cpu().numpy(), f2.grad.cpu().numpy(), atol=1e-5)
+
+
+def _host_metrics(gt, pred, ptype, gtype, points_dev):
+    """the per-cloud reference-surface function (host Hungarian) on copies of the arrays (it folds types in place)"""
+    import torch as T
+    from src.segment_utils import SIOU_matched_segments_usecd
+    w = T.nn.functional.one_hot(T.from_numpy(pred.astype(np.int64)), 50).float().cuda()
+    return SIOU_matched_segments_usecd(gt.astype(np.int64), pred.astype(np.int64), ptype.astype(np.int64).copy(),
+                                       gtype.astype(np.int64).copy(), w, points_dev)
+
+
+def _assignment_cost(gt, pred, cols, K=50):
+    """total cost of an assignment on the reference's cost matrix (relaxed IoU in fp32, 1 - cost)"""
+    import torch as T
+    from src.segment_utils import relaxed_iou_fast, to_one_hot
+    cost = 1.0 - relaxed_iou_fast(to_one_hot(pred.astype(np.int64)).cpu().unsqueeze(0).float(),
+                                  to_one_hot(gt.astype(np.int64)).cpu().unsqueeze(0).float())[0].numpy()
+    return float(cost[np.arange(K), cols].astype(np.float64).sum()), cost
+
+
+def test_batched_device_metrics_match_the_reference_fixture(T, golden):
+    """SIOU_matched_segments_usecd_batch (tables, Hungarian assignment by one wave per cloud, pair chamfer, means: all on the device)
+    on the cloud the reference's own class was run on (F-CD): the three logged numbers equal the reference's, and the device's
+    assignment is an optimum of the reference's cost matrix (rows with a non-empty side match the reference's exactly)."""
+    from src.segment_utils import SIOU_matched_segments_usecd_batch
+    g = golden("f_chamfer")
+    dev = lambda a: T.from_numpy(np.ascontiguousarray(a)).cuda()[None]
+    s, p, col, pairs, rec = SIOU_matched_segments_usecd_batch(dev(g["m_labels"].astype(np.int32)), dev(g["m_pred"].astype(np.int32)),
+                                                              dev(g["m_ptype"].astype(np.int32)), dev(g["m_types"].astype(np.int32)),
+                                                              dev(g["m_points"]))
+    np.testing.assert_allclose([s.item(), p.item(), rec.item()], g["m_result"], rtol=1e-6)
+    col = col[0].cpu().numpy()
+    assert sorted(col.tolist()) == list(range(50))
+    tot_dev, cost = _assignment_cost(g["m_labels"], g["m_pred"], col)
+    tot_ref = float(cost[g["m_rows"], g["m_cols"]].astype(np.float64).sum())
+    assert abs(tot_dev - tot_ref) < 1e-9
+    live = (np.bincount(g["m_pred"].astype(np.int64), minlength=50) > 0)
+    live_pair = live & (np.bincount(g["m_labels"].astype(np.int64), minlength=50)[g["m_cols"]] > 0)
+    np.testing.assert_array_equal(col[live_pair], g["m_cols"][live_pair])
+
+
+@pytest.mark.parametrize("seed,nseg_p,nseg_g", [(0, 12, 9), (1, 50, 50), (2, 3, 40), (3, 1, 1), (4, 30, 31)])
+def test_batched_device_metrics_equal_the_host_function(T, seed, nseg_p, nseg_g):
+    """Random labelings (empty segments, near-duplicate segments whose costs tie, 50 x 50 full, one segment): per cloud the device's
+    numbers equal the host function's (scipy assignment) and its assignment has the same total cost."""
+    from src.segment_utils import SIOU_matched_segments_usecd_batch
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(seed)
+    B, N = 3, 3000
+    pts = rng.normal(size=(B, N, 3)).astype(np.float32) * 0.3
+    gt = rng.integers(0, nseg_g, size=(B, N))
+    gt = rng.permutation(50)[gt]                                                   # label ids spread over 0 .. 49
+    centres = rng.normal(size=(B, 50, 3)).astype(np.float32)
+    pts += centres[np.arange(B)[:, None], gt] * (1.0 if seed != 4 else 0.02)      # seed 4: overlapping sets -> chamfer below 0.2
+    noise = rng.random((B, N)) < 0.2
+    pred = np.where(noise, rng.integers(0, nseg_p, size=(B, N)), gt % nseg_p)
+    pred[:, : N // 2] = np.where(pred[:, : N // 2] == 1, 0, pred[:, : N // 2])     # ties: halves of a segment merged
+    ptype, gtype = rng.integers(0, 10, size=(B, N)), rng.integers(0, 10, size=(B, N))
+    dv = lambda a: T.from_numpy(np.ascontiguousarray(a.astype(np.int32))).cuda()
+    P = T.from_numpy(pts).cuda()
+    s, p, col, pairs, rec = SIOU_matched_segments_usecd_batch(dv(gt), dv(pred), dv(ptype), dv(gtype), P)
+    checked_p = []
+    for b in range(B):
+        hs, hp, hm, hpairs, hrec = _host_metrics(gt[b], pred[b], ptype[b], gtype[b], P[b])
+        tot_dev, cost = _assignment_cost(gt[b], pred[b], col[b].cpu().numpy())
+        r, c = linear_sum_assignment(cost)
+        assert abs(tot_dev - float(cost[r, c].astype(np.float64).sum())) < 1e-9, (b, tot_dev)
+        np.testing.assert_allclose([s[b].item(), rec[b].item()], [hs, hrec], rtol=1e-9, atol=1e-12)
+        # the type IoU (gt type == predicted type over the matched pairs with two non-empty sides) depends on WHICH optimum was taken
+        # only through pairs without overlap (cost exactly 1: ties): equal whenever both solvers chose the same non-empty pairs
+        npred, ngt = np.bincount(pred[b], minlength=50), np.bincount(gt[b], minlength=50)
+        live = lambda cols: {(r_, int(c_)) for r_, c_ in enumerate(cols) if npred[r_] > 0 and ngt[c_] > 0}
+        same_pairs = live(col[b].cpu().numpy()) == live(hm[0][1])
+        checked_p.append(same_pairs)
+        if same_pairs:
+            np.testing.assert_allclose(p[b].item(), hp, rtol=1e-12)
+            assert [list(map(int, q)) for q in pairs[b].cpu().numpy() if q[0] >= 0] == [list(map(int, q)) for q in hpairs]
+    assert any(checked_p) or nseg_p * nseg_g > 1000
+
+
+def test_batched_device_metrics_refuse_labels_out_of_range(T):
+    from src.segment_utils import SIOU_matched_segments_usecd_batch
+    z = T.zeros(1, 100, dtype=T.int32).cuda()
+    bad = z.clone()
+    bad[0, 7] = 50
+    with pytest.raises(ValueError):
+        SIOU_matched_segments_usecd_batch(z, bad, z, z, T.zeros(1, 100, 3).cuda())

@@ -234,12 +234,17 @@ __global__ __launch_bounds__(256, 2) void knn_sweep_kernel(const float* __restri
     }
 }
 
+typedef float f32x8u __attribute__((ext_vector_type(8), aligned(4)));      // 8 consecutive floats at any dword address
+
 // ---- first-layer metric Dp (1 + W Dn) on xyz + normals (VALU; one thread per query) -----------------------------
 template <int M, int PASS>
 __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restrict__ x6, int N, int k, float W,
                                                            uint32_t* __restrict__ Tbuf, Cand* __restrict__ lists,
                                                            int* __restrict__ counts, int* __restrict__ overflow) {
-    __shared__ float ks[2][32][8];
+    // The 32 keys of a tile are the same for every lane: their coordinates and normals come through the SCALAR cache (uniform
+    // addresses -> s_load), only their squared norms (computed once per tile, like the reference's xx) go through LDS, four per
+    // read. Round 3 read 2 x 16 bytes of LDS per key and lane-uniformly: the CU's LDS unit was 80 % busy and bounded the kernel.
+    __shared__ __attribute__((aligned(16))) float kxx[2][32];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float* xc = x6 + (size_t)cloud * 6 * N;
     const int qi = blockIdx.x * 256 + tid;
@@ -271,13 +276,9 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     auto stage = [&](int tile, int buf) {
         if (tid < 32) {
             int j = tile * 32 + tid;
-            const bool ok = j < N;
-            j = ok ? j : N - 1;
+            j = j < N ? j : N - 1;
             const float a0 = xc[j], a1 = xc[N + j], a2 = xc[2 * N + j];
-            ks[buf][tid][0] = a0; ks[buf][tid][1] = a1; ks[buf][tid][2] = a2;
-            ks[buf][tid][3] = xc[3 * N + j]; ks[buf][tid][4] = xc[4 * N + j]; ks[buf][tid][5] = xc[5 * N + j];
-            ks[buf][tid][6] = __fadd_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)), __fmul_rn(a2, a2));
-            ks[buf][tid][7] = ok ? 1.f : 0.f;
+            kxx[buf][tid] = __fadd_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)), __fmul_rn(a2, a2));
         }
     };
     stage(t0, 0);
@@ -291,15 +292,29 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
         const bool ragged = tile * 32 + 32 > N;
         auto values = [&](auto ragged_c) {
             constexpr bool RAGGED = decltype(ragged_c)::value;
+            f32x4 xx4[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) xx4[g] = *(const f32x4*)&kxx[cur][4 * g];
+            f32x8u kv[6];
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
-                const float* kq = ks[cur][r];
-                const float dotp = fmaf(p2, kq[2], fmaf(p1, kq[1], __fmul_rn(p0, kq[0])));
-                const float dotn = fmaf(n2, kq[5], fmaf(n1, kq[4], __fmul_rn(n0, kq[3])));
-                const float dp = __fadd_rn(__fsub_rn(kq[6], 2.0f * dotp), xxi);          // (xx_j - inner) + xx_i  (:109)
+                const bool pad = RAGGED && tile * 32 + r >= N;
+                float k0, k1, k2, k3, k4, k5;
+                if (RAGGED) {
+                    const int j = pad ? N - 1 : tile * 32 + r;                          // uniform: scalar loads
+                    k0 = xc[j]; k1 = xc[N + j]; k2 = xc[2 * N + j]; k3 = xc[3 * N + j]; k4 = xc[4 * N + j]; k5 = xc[5 * N + j];
+                } else {
+                    if ((r & 7) == 0) {                                                  // 8 keys of a channel per s_load_dwordx8
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) kv[c] = *(const f32x8u*)(xc + (size_t)c * N + tile * 32 + r);
+                    }
+                    k0 = kv[0][r & 7]; k1 = kv[1][r & 7]; k2 = kv[2][r & 7]; k3 = kv[3][r & 7]; k4 = kv[4][r & 7]; k5 = kv[5][r & 7];
+                }
+                const float dotp = fmaf(p2, k2, fmaf(p1, k1, __fmul_rn(p0, k0)));
+                const float dotn = fmaf(n2, k5, fmaf(n1, k4, __fmul_rn(n0, k3)));
+                const float dp = __fadd_rn(__fsub_rn(xx4[r >> 2][r & 3], 2.0f * dotp), xxi);   // (xx_j - inner) + xx_i  (:109)
                 const float dn = __fsub_rn(2.0f, 2.0f * dotn);                           // :112
                 const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));       // :115
-                const bool pad = RAGGED && kq[7] == 0.f;
                 if (PASS == 1) {
                     float v = pad ? 3.0e38f : dv;
 #pragma unroll

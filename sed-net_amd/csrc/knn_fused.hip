@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     // The 32 keys of a tile are the same for every lane: their coordinates and normals come through the SCALAR cache (uniform
     // addresses -> s_load), only their squared norms (computed once per tile, like the reference's xx) go through LDS, four per
     // read. Round 3 read 2 x 16 bytes of LDS per key and lane-uniformly: the CU's LDS unit was 80 % busy and bounded the kernel.
+    // Every rounding of the metric is written out (hipcc contracts a * b + c into an fma wherever it likes, also through
+    // __fmul_rn / __fadd_rn, and not the same way in every instantiation): contraction is off in this function and the fmas below are
+    // the ones the round-3 build of this kernel and pairwise.hip's materialised form perform, so that the two keep agreeing bit for bit.
+#pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float kxx[2][32];
     const int cloud = blockIdx.y, tid = threadIdx.x;
     const float* xc = x6 + (size_t)cloud * 6 * N;
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
     const int qc = qi < N ? qi : N - 1;
     const float p0 = xc[qc], p1 = xc[N + qc], p2 = xc[2 * N + qc];
     const float n0 = xc[3 * N + qc], n1 = xc[4 * N + qc], n2 = xc[5 * N + qc];
-    const float xxi = __fadd_rn(__fadd_rn(__fmul_rn(p0, p0), __fmul_rn(p1, p1)), __fmul_rn(p2, p2));
+    auto sqnorm3 = [](float a0, float a1, float a2) { return fmaf(a2, a2, fmaf(a0, a0, a1 * a1)); };
+    const float xxi = sqnorm3(p0, p1, p2);
     const int ntiles = (N + 31) >> 5;
 
     // bucket minima as floats, float prefilter in sweep 2, padding tests only in the last tile: see knn_sweep_kernel
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
             int j = tile * 32 + tid;
             j = j < N ? j : N - 1;
             const float a0 = xc[j], a1 = xc[N + j], a2 = xc[2 * N + j];
-            kxx[buf][tid] = __fadd_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)), __fmul_rn(a2, a2));
+            kxx[buf][tid] = sqnorm3(a0, a1, a2);
         }
     };
     stage(t0, 0);
@@ -310,11 +315,11 @@ __global__ __launch_bounds__(256) void knn_pn_sweep_kernel(const float* __restri
                     }
                     k0 = kv[0][r & 7]; k1 = kv[1][r & 7]; k2 = kv[2][r & 7]; k3 = kv[3][r & 7]; k4 = kv[4][r & 7]; k5 = kv[5][r & 7];
                 }
-                const float dotp = fmaf(p2, k2, fmaf(p1, k1, __fmul_rn(p0, k0)));
-                const float dotn = fmaf(n2, k5, fmaf(n1, k4, __fmul_rn(n0, k3)));
-                const float dp = __fadd_rn(__fsub_rn(xx4[r >> 2][r & 3], 2.0f * dotp), xxi);   // (xx_j - inner) + xx_i  (:109)
-                const float dn = __fsub_rn(2.0f, 2.0f * dotn);                           // :112
-                const float dv = __fmul_rn(dp, __fadd_rn(1.0f, __fmul_rn(dn, W)));       // :115
+                const float dotp = fmaf(p2, k2, fmaf(p1, k1, p0 * k0));
+                const float dotn = fmaf(n2, k5, fmaf(n1, k4, n0 * k3));
+                const float dp = (xx4[r >> 2][r & 3] - 2.0f * dotp) + xxi;               // (xx_j - inner) + xx_i  (:109)
+                const float dn = 2.0f - 2.0f * dotn;                                     // :112
+                const float dv = dp * (RAGGED ? 1.0f + dn * W : fmaf(W, dn, 1.0f));      // :115 (a cloud's last, ragged tile: two roundings)
                 if (PASS == 1) {
                     float v = pad ? 3.0e38f : dv;
 #pragma unroll

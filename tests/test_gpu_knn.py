@@ -215,3 +215,20 @@ def test_every_mismatch_at_10k_is_a_near_tie(T, metric, k):
     ref = np.argsort(-score, axis=1, kind="stable")[:, :k]
     # (k = 64 on real features: most rows hold SOME near-tie among 64 neighbours, the exact-list rate is not the statement here)
     check_idx(got[rows], ref, score, k, scale if metric == "feat" else None, min_same=0.8)
+
+
+@pytest.mark.parametrize("N", [1501, 4099])
+def test_first_layer_graph_on_odd_cloud_sizes_equals_the_materialised_path(T, N):
+    """knn_pn_sweep_kernel reads a tile's key coordinates with 8-wide SCALAR loads at channel offsets c N: for odd N those are only
+    dword-aligned. Same neighbours as the materialised path (pairwise.hip + select.hip), k = 20 and 64."""
+    from sednet_hip import ops, synth
+    from src.PointNet import knn_points_normals
+    x6 = T.from_numpy(synth.batch_clouds(3, N, seed0=5)[0]).cuda()
+    for k in (20, 64):
+        fused = knn_points_normals(x6, k, k).cpu().numpy()
+        ops.FUSED_KNN = False
+        try:
+            exact = knn_points_normals(x6, k, k).cpu().numpy()
+        finally:
+            ops.FUSED_KNN = True
+        np.testing.assert_array_equal(fused, exact)

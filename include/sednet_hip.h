@@ -177,16 +177,18 @@ int sed_fps_pivots_f32(int B, int N, int d, int stride, int P, const float* X, i
  * workspace. form, a bit set: bit 0 = a cloud's items in row order instead of longest first (neighbouring items = queries of the
  * same clusters run at the same time: a smaller working set per L2); bit 1 = ONE resident workgroup per CU instead of two (a
  * measurement switch); bit 2 = (d = 160 only) the 512-register build of the kernel with one workgroup per CU (a measurement switch:
- * profiles/r05_sparse_d160.md); 0 = default; anything above 7 is SED_EINVAL. An item's result does not depend on any other item: a cloud's
+ * DESIGN.md Appendix A); 0 = default; anything above 7 is SED_EINVAL. An item's result does not depend on any other item: a cloud's
  * rows are the same bits whatever else is in the call and whichever form queues it. Clouds whose rows are not unit vectors run
  * the exact dense fp32 kernel. N <= 16 384; d = 128, or 160 (rows padded from the HPNet flow's 140 columns); iters = 0 copies
  * the rows.
- * stop_below (ABI 6; 0 = off, at most 1e-3): a wave whose 32 queries have ALL moved by a chord <= stop_below in one iteration has
- * arrived at its fixed point: its rows are written as they are and it executes no further block (an item whose four waves have
- * arrived ends). The reference has no such test (it always runs `iterations` steps, mean_shift.py:45-79); at 1e-6 -- where an fp32
- * row's step is rounding noise: consecutive iterates of a converged row differ by 3e-7 .. 1e-6 -- the rows end within 3e-6 of where
- * 50 steps take them (profiles/r05_freeze_probe.md). The decision depends on the wave's own queries only: rows stay a function of
- * the cloud. */
+ * stop_below (ABI 6; 0 = off, at most 1e-3; an EXPERIMENT beside the contract -- the reference has no such test, it always runs
+ * `iterations` steps, mean_shift.py:45-79 -- and off in every default): a WORK ITEM (128 query rows, four waves) all of whose queries
+ * have moved by a chord <= stop_below in one iteration ends there: its rows are written as they are. The decision is per item, not
+ * per wave: an item's loop bound is cut only when all of its waves' largest steps are at or below the threshold, so with stop_below > 0
+ * a row depends on the item's 128 queries and the "bit-identical with 4 / 2 / 1 waves per item" property of the kernel holds for
+ * stop_below = 0 only. Rows stay a function of the cloud alone (an item never looks at another cloud). At 5e-6 -- about the step the
+ * kernel's chained fp32 accumulation keeps producing at a fixed point -- the iteration launch of the benchmark step is 12 % shorter
+ * and 57 of 64 bench clouds keep their labels (profiles/r05_stop_below.md, profiles/r05_freeze_probe.md). */
 int sed_ms_iterate_bounds_f16_refs(int N);
 int sed_ms_iterate_bounds_f16_stats_words(void);
 size_t sed_ms_iterate_bounds_f16_workspace_bytes(int B, int N);

@@ -215,7 +215,10 @@ __global__ __launch_bounds__(1024) void tree_sort_kernel(const float* __restrict
     for (int g = tid; g < ntiles; g += 1024) {
         const int s = ns[g], e = ne[g];
         if (e - s <= 32) continue;
-        const int cut = 32 * (0xffff - (int)(best[s >> 5] & 0xffffull));
+        int cut = 32 * (0xffff - (int)(best[s >> 5] & 0xffffull));
+        //  the [lo, hi] boundary arithmetic above posts at least one candidate for every node that splits; should `best` ever
+        // stay 0 the cut falls outside the node -- take the median tile boundary then instead of corrupting the node table
+        if (cut <= s || cut >= e) cut = s + 32 * (((e - s + 31) >> 5) >> 1);
         if (32 * g < cut) { nc[2 * g] = s; nc[2 * g + 1] = cut; }
         else { nc[2 * g] = cut; nc[2 * g + 1] = e; }
     }

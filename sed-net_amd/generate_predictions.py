@@ -132,9 +132,16 @@ def main(argv=None):
                     help="fp16 digits of the kernel weights in the mean-shift iterations' second product (sednet_hip.ops."
                          "ms_set_weight_digits): 2 = (h, l) pairs, fp32-equivalent (default); 1 = fp16 heads, 5 instead of 6 "
                          "MFMAs per block pair, 14 %% faster, ~0.2 %% of the labels move on a trained network's embedding")
-    ap.add_argument("--ms-stop-below", type=float, default=0.0,
+    ap.add_argument("--ms-exact", choices=["off", "batched", "chunked"], default="off",
+                    help="exact-parity mode of the clustering stage (sednet_hip.ops.ms_set_variant): run the 50 mean-shift iterations on the "
+                         "exact fp32 MFMA kernel instead of the split-fp16 block-sparse schedule -- the reference's own arithmetic "
+                         "(src/mean_shift.py:56-77) in one of two fp32 summation orders. With the reference's kNN graphs, 'chunked' returns "
+                         "the reference's labels bit for bit on 4 of 8 bench clouds and 'batched' on a fifth; ~4 x the iteration time "
+                         "(profiles/r06_exact_mode.md)")
+    ap.add_argument("--ms-stop-below", type=float, default=None,
                     help="arrival test of the block-sparse mean-shift kernel (sednet_hip.ops.MS_SPARSE_STOP): a work item whose 128 "
-                         "queries all moved by a chord <= this in one iteration ends there; 0 (default) = always 50 iterations like "
+                         "queries all moved by a chord <= this in one iteration ends there; not given = ops.MS_SPARSE_STOP as it is (0 unless "
+                         "SED_MS_SPARSE_STOP is set) = always 50 iterations like "
                          "the reference (src/mean_shift.py:45-79); 5e-6 takes ~12 %% off the iteration launch of the benchmark step")
     args = ap.parse_args(argv)
     if not args.input and not args.synthetic:
@@ -149,7 +156,10 @@ def main(argv=None):
     model_inst = build_model(config.knn, config.pretrain_model_type_path, 1, device, log, args.synthetic_weights)    # :196-198
     ms = MeanShift()
     ops.ms_set_weight_digits(args.ms_weight_digits)
-    ops.MS_SPARSE_STOP = float(args.ms_stop_below)
+    if args.ms_exact != "off":
+        ops.ms_set_variant(args.ms_exact)
+    if args.ms_stop_below is not None:                     # (the flag's default used to overwrite SED_MS_SPARSE_STOP)
+        ops.MS_SPARSE_STOP = float(args.ms_stop_below)
     x_all, labels_all, types_all, ids = load_clouds(args)
     if args.save == "Save":
         os.makedirs(args.out, exist_ok=True)

@@ -362,9 +362,50 @@ def ms_near_fraction(X, bw, skip_below=-30.0, rows=64, keys=512):
 
 
 import os as _os
+# Debug canary: SED_TEST_FINITE=1 makes every stage of SegmentationPipeline.__call__ and
+# MeanShift.mean_shift_batch end with a finiteness check of its outputs (finite_canary below: one reduction + one host sync per stage --
+# a debugging run, never a timed one). A non-finite value raises with the stage's name and dumps the offending cloud's stage inputs /
+# outputs to SED_TEST_FINITE_DUMP (default gpurun_out/finite_canary_<stage>.npz) so that the run that produced it can be replayed.
+FINITE_CANARY = _os.environ.get("SED_TEST_FINITE", "0") not in ("", "0")
+FINITE_CHECKS = {"stages": 0}
+
+
+def finite_canary(stage, outputs, inputs=None):
+    """outputs / inputs: dicts name -> device tensor with a leading cloud dimension (floating tensors are tested with isfinite, integer
+    ones pass). Raises FloatingPointError naming the stage, the tensor and the first offending cloud."""
+    if not FINITE_CANARY:
+        return
+    import numpy as np
+    FINITE_CHECKS["stages"] += 1
+    for name, t in outputs.items():
+        if t is None or not torch.is_tensor(t) or not t.is_floating_point():
+            continue
+        ok = torch.isfinite(t.reshape(t.shape[0], -1)).all(dim=1) if t.dim() > 1 else torch.isfinite(t)
+        if bool(ok.all()):
+            continue
+        bad = int(torch.nonzero(~ok)[0, 0])
+        path = _os.environ.get("SED_TEST_FINITE_DUMP") or _os.path.join(
+            _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "gpurun_out",
+            f"finite_canary_{stage}.npz")
+        try:
+            _os.makedirs(_os.path.dirname(path), exist_ok=True)
+            dump = {}
+            for kind, d in (("out", outputs), ("in", inputs or {})):
+                for k, v in d.items():
+                    if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] > bad:
+                        dump[f"{kind}_{k}"] = v[bad].detach().cpu().numpy()
+            np.savez_compressed(path, cloud=np.int64(bad), **dump)
+        except Exception as e:                                       # the dump must never mask the finding
+            path = f"(dump failed: {e!r})"
+        n_bad = int((~torch.isfinite(t[bad])).sum())
+        raise FloatingPointError(f"SED_TEST_FINITE: stage '{stage}' produced {n_bad} non-finite values in '{name}' of cloud {bad} "
+                                 f"(of {t.shape[0]}); stage inputs / outputs of that cloud dumped to {path}")
+
+
 MS_PREP_PIVOTS = int(_os.environ.get("SED_MS_PREP_PIVOTS", "0"))       # 0 = split-tree row order (round 5); 1 .. 64 = the farthest-point-pivot order of rounds 2-4 (A/B)
-# sed_ms_iterate_bounds_f16_f32's stop_below: a wave of the block-sparse kernel whose 32 queries all moved by a chord <= this in one
-# iteration is at its fixed point and executes nothing further (0 = off: always `iterations` steps like mean_shift.py:45-79)
+# sed_ms_iterate_bounds_f16_f32's stop_below (an experiment beside the contract, off by default): a WORK ITEM of the block-sparse kernel
+# (128 query rows) all of whose queries moved by a chord <= this in one iteration ends there (0 = off: always `iterations` steps like
+# mean_shift.py:45-79). Per item, not per wave: the kernel's independence of the workgroup shape holds for 0 only.
 MS_SPARSE_STOP = float(_os.environ.get("SED_MS_SPARSE_STOP", "0"))
 
 

@@ -205,8 +205,22 @@ class SegmentationPipeline:
             self._spec.wait_stream(main)
             far_flags = []
             with torch.cuda.stream(self._spec):
+                #  the chain's own duration, taken on ITS stream: it overlaps the forwards, so it appears in stage_times as an
+                # extra entry ("hpnet_spectral_overlapped") beside the main stream's stages, whose sum stays the step; the "hpnet" stage
+                # below is only what is left after the join (feature entropy + concatenation). Memory: the chain's intermediates
+                # (far-kNN workspaces, CSR, LOBPCG blocks for all clouds of the call) live in this stream's own pool of the caching
+                # allocator and are not reused by the main stream -- ~1.2 GB at 64 x 10 000 points on top of the step's ~9 GB.
+                if self.stage_times is not None:
+                    s0 = torch.cuda.Event(enable_timing=True)
+                    s0.record()
                 spectral = hpnet_spectral(pts_h, nrm_h, 0.5, 1000, flags=far_flags)
+                if self.stage_times is not None:
+                    s1 = torch.cuda.Event(enable_timing=True)
+                    s1.record()
+                    self.stage_times.append(("hpnet_spectral_overlapped", s0, s1))
         log_prob, t_model, emb, edges, X = self._forwards_checked(x6, ev)
+        ops.finite_canary("forwards", {"log_prob": log_prob, "embedding": emb, "edges": edges}, {"x6": x6})
+        ops.finite_canary("row_normalize", {"X": X}, {"embedding": emb})
         if embedding is not None:
             X = ops.row_normalize(embedding.float().contiguous(), embedding.shape[2])
         types = t_model if types is None else types.int().contiguous()
@@ -222,6 +236,7 @@ class SegmentationPipeline:
                                  x6[:, 3:6].transpose(1, 2).contiguous(), normal_smooth_w=0.5, CHUNK=1000,
                                  spectral=spectral)                                                           # :59, :375
             X = ops.row_normalize(wide.contiguous(), wide.shape[2])                                           # :377
+            ops.finite_canary("hpnet", {"wide": wide, "X": X}, {"embedding": emb, "x6": x6})
             ev.mark("hpnet")
         labels, bw, n_labels, passes = self.ms.guard_mean_shift_batch(X, self.quantile, self.iterations, dist=self.dist)
         ev.mark("mean_shift")
@@ -233,5 +248,8 @@ class SegmentationPipeline:
             params, valid = ops.fit_segments(pts, nrm, seg_type, labels=labels)
             _, seg_res = ops.residual_segments(pts, seg_type, params, valid, labels=labels, sqrt=True, per_point=False)
             out.update(seg_type=seg_type, seg_count=seg_count, params=params, valid=valid, seg_residual=seg_res)
+            ops.finite_canary("fits", {"params": torch.where(valid.bool().unsqueeze(-1), params, torch.zeros_like(params)),
+                                       "seg_residual": torch.where(valid.bool(), seg_res, torch.zeros_like(seg_res))},
+                              {"x6": x6, "labels": labels, "types": types})
             ev.mark("fits")
         return out

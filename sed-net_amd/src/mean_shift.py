@@ -107,8 +107,14 @@ class MeanShift:
                 sub = torch.stack([self._subset(N, num_samples, X.device) for _ in range(B)])
                 Xs, bprep = torch.gather(Xp, 1, sub.unsqueeze(-1).expand(B, num_samples, Xp.shape[2])), None
             bw = ops.ms_bandwidth(Xs.contiguous(), K, 0.003, prep=bprep)
+            ops.finite_canary("ms_bandwidth", {"bw": bw}, {"X": Xp})
         new_Xp = ops.ms_iterate(Xp, bw, iterations, prep=prep)
+        ops.finite_canary("ms_iterate", {"new_X": new_Xp}, {"X": Xp, "bw": bw})
         labels, ids, n_c, n_l = ops.ms_nms(new_Xp, Xp, bw, prep=prep)
+        if ops.FINITE_CANARY:                    # nms: integer outputs -- labels must be valid segment ids, one centre at least
+            bad = (labels < 0) | (labels >= N)
+            if bool(bad.any()) or bool((n_l <= 0).any()):
+                ops.finite_canary("ms_nms", {"labels_invalid": torch.where(bad, float("nan"), 0.0)}, {"new_X": new_Xp, "X": Xp, "bw": bw})
         return new_Xp[:, :, :d], bw, labels, ids, n_c, n_l
 
     def guard_mean_shift_batch(self, X, quantile, iterations, num_samples=10000, factor=1.2, max_clusters=49,

@@ -84,7 +84,7 @@ def test_fit_skips_and_all_points_one_segment(T):
     assert float(res[0, 0]) < 1e-9 and float(res[0, 1]) == 0.0
 
 
-def test_non_finite_rows_never_become_addresses(T):
+def test_non_finite_rows_never_become_addresses(T, monkeypatch):
     """Garbage in, garbage out -- but no device fault: a point with NaN coordinates (or an embedding row of NaNs) compares below no
     threshold, so the index-producing kernels used to leave their sentinels (membership: 0x7fffffff) or stale words of the output
     buffer (kNN finalize: rows with fewer than k candidates) where the next kernel reads an address. Now: such kNN rows are flagged
@@ -93,6 +93,7 @@ def test_non_finite_rows_never_become_addresses(T):
     from sednet_hip import ops, synth
     from src.mean_shift import MeanShift
     from src.PointNet import knn
+    monkeypatch.setattr(ops, "FINITE_CANARY", False)          # this test feeds non-finite rows on purpose (a SED_TEST_FINITE=1 run would stop at them)
     N = 900
     rng = np.random.default_rng(5)
     f = rng.normal(size=(2, 64, N)).astype(np.float32)
@@ -112,3 +113,30 @@ def test_non_finite_rows_never_become_addresses(T):
     assert lab_b.min() >= 0 and lab_b.max() < N
     for c in (0, 2):                                          # the clouds beside the poisoned one: the same bits
         assert (lab_b[c] == lab_c[c].cpu().numpy()).all() and float(bw_b[c]) == float(bw_c[c])
+
+
+def test_finite_canary_names_the_stage_and_the_cloud(T, tmp_path, monkeypatch):
+    """SED_TEST_FINITE (ops.FINITE_CANARY): every stage of the pipeline and of MeanShift.mean_shift_batch ends with a
+    finiteness check of its outputs; a non-finite value raises with the stage's name, the tensor, the cloud, and dumps that cloud's
+    stage inputs / outputs. A clean batch passes all checks (and they are counted, so the switch cannot silently do nothing); an
+    embedding with a poisoned row is caught at the stage that first turns it into an output (the iterations), not at the host copy of
+    the guard loop three stages later."""
+    from sednet_hip import ops, synth
+    from src.mean_shift import MeanShift
+    N = 900
+    Xs = np.stack([synth.clustered_embedding(N=N, d=128, n_clusters=4 + c, sigma=0.02, seed=40 + c)[0] for c in range(3)])
+    monkeypatch.setattr(ops, "FINITE_CANARY", True)
+    monkeypatch.setenv("SED_TEST_FINITE_DUMP", str(tmp_path / "canary.npz"))
+    n0 = ops.FINITE_CHECKS["stages"]
+    ms = MeanShift()
+    ms.mean_shift_batch(T.from_numpy(Xs).cuda(), 10000, 0.015, 20)
+    assert ops.FINITE_CHECKS["stages"] >= n0 + 2                      # bandwidth, iterate (+ the integer check of nms)
+    bad = Xs.copy()
+    bad[1, 100:140] = np.nan
+    with pytest.raises(FloatingPointError) as e:
+        ms.mean_shift_batch(T.from_numpy(bad).cuda(), 10000, 0.015, 20)
+    msg = str(e.value)
+    assert ("'ms_iterate'" in msg or "'ms_bandwidth'" in msg) and "cloud 1 " in msg, msg
+    d = np.load(tmp_path / "canary.npz")
+    assert int(d["cloud"]) == 1 and np.isnan(d["in_X"]).any()
+    T.cuda.synchronize()

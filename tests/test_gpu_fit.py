@@ -1,9 +1,12 @@
 """GPU parity: batched primitive fits + residuals vs golden vectors captured from the reference
 (tolerances: 1e-4 relative on well-posed quantities; the reference's own ill-conditioned outputs are compared
 through their well-defined invariants, see tests/test_oracle_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 PLANE, CONE, CYLINDER, SPHERE = 1, 3, 4, 5
 
@@ -303,3 +306,116 @@ def test_cylinder_exception_proves_itself(T, golden, capsys):
         print("\ncylinder fits under a 1-ulp perturbation of the points: reference |dc| median %.1e max %.1e, |dr| max %.1e; "
               "HIP |dc| max %.1e, |dr| max %.1e" % (np.median(ref_dc), ref_dc.max(), ref_dr.max(), hip_dc.max(), hip_dr.max()))
     assert hip_dc.max() < 5e-4 and hip_dr.max() < 5e-4 and hip_dc.max() < 0.01 * ref_dc.max() and np.median(hip_dc) < 0.01 * np.median(ref_dc)
+
+
+def test_fits_on_the_bench_segments_match_the_reference(T, golden, capsys):
+    """VERDICT r5 missing 1 / weak 2: the contract's "primitive parameters within 1e-4 rel" ON THE BENCH WORKLOAD. tests/golden/f_64_fit.npz
+    (make_64_fit.py) holds the reference's eval-mode fit caller (src/primitive_forward.py:929-1051 -> Fit.fit_*_torch :712-847 ->
+    LeastSquares.lstsq src/fitting_utils.py:36-85, residuals src/primitives.py:89-195) on the reference's OWN labels and types of all 64
+    bench clouds (f_64.npz): 831 segments the trained network really produces -- mixed, unlike f_fit's clean patches --, 776 fitted,
+    96 through the ridge branch (every cylinder: the projected system has rank 2), 16 cone bail-outs (cond > 1e5), 55 skipped (< 20
+    points). With those labels and types INJECTED, one launch each of the device's type vote, fits and residuals over the 64 x 10 000
+    batch must: vote the reference's type on every segment (stats.mode, residual_utils.py:259), take the same branch on every
+    segment (valid mask, bail-out parameters exact), and return plane / sphere / cone parameters and the residuals to 1e-4 relative.
+    Cylinders (row a13's documented exception): axis 1e-4; centre / radius against the noise-free limit of the same estimator (oracle
+    fit_cylinder_exact) 1e-4, reported against the reference, and not worse on average in the reference's own residual.
+    Report -> gpurun_out/r06_fits_on_bench_segments.md."""
+    import os
+    from fit64_common import (BR_CONE_BAIL, BR_RIDGE, BR_SKIPPED, TOL, compare_segment, perp_centre_radius, reference_segments, rel)
+    from oracle import fit as ofit
+    from sednet_hip import ops, synth
+    g, g64 = golden("f_64_fit"), golden("f_64")
+    seeds = [int(s) for s in g["seeds"]]
+    B, N, S = len(seeds), 10000, 50
+    x = synth.batch_clouds(B, N, seed0=seeds[0])[0].astype(np.float32)
+    labels = np.zeros((B, N), np.int32)
+    types = np.zeros((B, N), np.int32)
+    for b, seed in enumerate(seeds):
+        assert abs(x[b].astype(np.float64).sum() - float(g64[f"s{seed}_x_sum"])) < 1e-3
+        labels[b], types[b], _ = reference_segments(g, g64, seed)
+    x6 = dev(T, x)
+    P, Nn = x6[:, 0:3].transpose(1, 2).contiguous(), x6[:, 3:6].transpose(1, 2).contiguous()
+    L, Ty = dev(T, labels), dev(T, types)
+    seg_type, seg_count = ops.segment_type_vote(L, Ty, S, 10)
+    params, valid = ops.fit_segments(P, Nn, seg_type, labels=L)
+    _, seg_res = ops.residual_segments(P, seg_type, params, valid, labels=L, sqrt=True, per_point=False)
+    seg_type, seg_count, params, valid, seg_res = (t.cpu().numpy() for t in (seg_type, seg_count, params, valid, seg_res))
+    worst, counts = {}, {"segments": 0, "fitted": 0, "ridge": 0, "bail": 0, "skipped": 0}
+    cyl = []
+    res_err = {PLANE: 0.0, SPHERE: 0.0, CONE: 0.0}
+    pts = np.ascontiguousarray(x[:, 0:3].transpose(0, 2, 1))
+    nrm = np.ascontiguousarray(x[:, 3:6].transpose(0, 2, 1))
+    for b, seed in enumerate(seeds):
+        tag = f"s{seed}_"
+        K = int(g[tag + "K"])
+        np.testing.assert_array_equal(seg_type[b, :K], g[tag + "seg_type"][:K], err_msg=f"type vote, seed {seed}")
+        np.testing.assert_array_equal(seg_count[b, :K], g[tag + "seg_count"][:K])
+        assert (valid[b, K:] == 0).all()
+        for s in range(K):
+            br, kind = int(g[tag + "branch"][s]), int(seg_type[b, s])
+            counts["segments"] += 1
+            if br == BR_SKIPPED:
+                assert valid[b, s] == 0, (seed, s)
+                counts["skipped"] += 1
+                continue
+            assert valid[b, s] == 1, (seed, s)
+            counts["fitted"] += 1
+            counts["ridge"] += br == BR_RIDGE
+            counts["bail"] += br == BR_CONE_BAIL
+            q, ref = params[b, s, :7], g[tag + "params"][s]
+            is_bail = kind == CONE and float(q[6]) == 0.0 and q[3:6].tolist() == [1.0, 0.0, 0.0] and not q[0:3].any()
+            assert is_bail == (br == BR_CONE_BAIL), (seed, s, g[tag + "cond"][s])       # the same branch (:822-827)
+            for k, v in compare_segment(kind, br, q, ref).items():
+                if v > worst.get(k, (0.0,))[0]:
+                    worst[k] = (v, seed, s)
+            if kind != CYLINDER:
+                e = abs(float(seg_res[b, s]) - float(g[tag + "residual"][s])) / max(float(g[tag + "residual"][s]), 1e-2)
+                res_err[kind] = max(res_err[kind], e)
+                continue
+            # a13: the reference's (centre, radius) of a cylinder is its fp32 ridge solve of a cond ~ 1e6 system. Against the noise-free
+            # limit of the SAME estimator (fp64 reductions + solve on the same fp32 per-point terms) and in the reference's own residual:
+            sel = labels[b] == s
+            w = np.ones((int(sel.sum()), 1), np.float32) + np.finfo(np.float32).eps
+            ea, ec, er = ofit.fit_cylinder_exact(pts[b][sel], nrm[b][sel], w)
+            cp, rp, cpar = perp_centre_radius(ea, q[3:6], q[6])
+            ecp, erp, ecpar = perp_centre_radius(ea, ec, er)
+            rcp, rrp, rcpar = perp_centre_radius(ref[0:3], ref[3:6], ref[6])
+            cyl.append((np.abs(cp - ecp).max(), abs(rp - erp), abs(cpar), np.abs(cp - rcp).max(), abs(rp - rrp), abs(rcpar),
+                        abs(float(q[6]) - float(ref[6])), float(g[tag + "residual"][s]) - float(seg_res[b, s]), float(g[tag + "lambda"][s]),
+                        float(g[tag + "residual"][s]), int(sel.sum())))
+    cyl = np.array(cyl)
+    lines = [
+        "# Primitive fits on the bench workload's own segments against the reference (tests/test_gpu_fit.py, tests/golden/f_64_fit.npz)", "",
+        "The reference's labels and per-point types of all 64 bench clouds (f_64.npz) injected into ONE launch each of `segment_type_vote`, "
+        "`fit_segments`, `residual_segments` (64 x 10 000 points, 50 segment slots); the reference side is its eval-mode caller "
+        "`fit_one_shape_torch` (src/primitive_forward.py:929-1051) run segment by segment (tests/golden/make_64_fit.py).", "",
+        f"* segments: {counts['segments']} (the bench step's own labels give 772: the device finds fewer clusters on some clouds); fitted "
+        f"{counts['fitted']}, skipped (< 20 points) {counts['skipped']}, **ridge branch {counts['ridge']}** (every cylinder: rank 2 of 3; no "
+        f"sphere of the set is rank-deficient), **cone bail-outs (cond > 1e5) {counts['bail']}**",
+        "* type vote equal to `stats.mode` on every segment; valid mask and branch equal on every segment", "",
+        "| quantity | worst relative difference (|a - b| / max(1, |b|)) | at (seed, segment) |", "|---|---:|---|"]
+    for k in sorted(worst):
+        lines.append(f"| {k} | {worst[k][0]:.2e} | {worst[k][1]}, {worst[k][2]} |")
+    lines += [f"| mean sqrt-residual of a segment, plane / sphere / cone (relative to max(residual, 1e-2)) | {res_err[PLANE]:.2e} / "
+              f"{res_err[SPHERE]:.2e} / {res_err[CONE]:.2e} | |", "",
+              f"Cylinders ({cyl.shape[0]} segments, {int(cyl[:, 10].min())} .. {int(cyl[:, 10].max())} points; lambda chosen by the reference's `best_lambda`: "
+              f"{ {float(v): int((cyl[:, 8] == v).sum()) for v in np.unique(cyl[:, 8])} }; these are MIXED segments: the reference's residual on them is "
+              f"{np.median(cyl[:, 9]):.2e} median, {cyl[:, 9].max():.2e} max):", "",
+              f"* HIP vs the noise-free limit of the reference's estimator: |dc_perp| max {cyl[:, 0].max():.1e}, |dr_perp| max {cyl[:, 1].max():.1e}, "
+              f"axial centre component |c_par| max {cyl[:, 2].max():.1e}",
+              f"* HIP vs the reference: |dc_perp| median {np.median(cyl[:, 3]):.1e} max {cyl[:, 3].max():.1e}; |dr_perp| median {np.median(cyl[:, 4]):.1e} "
+              f"max {cyl[:, 4].max():.1e}; the reference's own |c_par| median {np.median(cyl[:, 5]):.1e} max {cyl[:, 5].max():.1e}; |dr| max {cyl[:, 6].max():.1e}",
+              f"* residual(reference) - residual(HIP) in the reference's own sqrt residual: min {cyl[:, 7].min():+.1e}, mean {cyl[:, 7].mean():+.1e}, "
+              f"max {cyl[:, 7].max():+.1e}; HIP lower on {int((cyl[:, 7] > 0).sum())} of {cyl.shape[0]} (on these mixed segments neither side is 'the' cylinder: the "
+              f"reference's axial noise lands on either side of the limit; on clean cylinders, f_cyl, the HIP residual is never worse)"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r06_fits_on_bench_segments.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with capsys.disabled():
+        print("\n" + "\n".join(lines[4:]))
+    assert counts["ridge"] >= 90 and counts["bail"] >= 10 and counts["skipped"] >= 50       # the branches the fixture is there for
+    assert max(v[0] for v in worst.values()) < TOL, worst
+    assert max(res_err.values()) < 2e-4, res_err
+    assert cyl[:, 0].max() < TOL and cyl[:, 1].max() < TOL, (cyl[:, 0].max(), cyl[:, 1].max())
+    # in the reference's own residual: not worse on average, and nowhere by more than 1 % of the segments' typical residual (3.5e-2)
+    assert cyl[:, 7].mean() >= 0 and cyl[:, 7].min() > -5e-4, (cyl[:, 7].mean(), cyl[:, 7].min())

@@ -313,6 +313,43 @@ def cyl_invariants(axis, c, r):
     return ax, c - cpar * ax, float(np.sqrt(max(float(r) ** 2 - cpar ** 2, 0.0))), cpar
 
 
+def test_fits_on_the_bench_segments_match_the_reference(golden):
+    """f_64_fit (VERDICT r5 missing 1): the reference's eval-mode fit caller (src/primitive_forward.py:929-1051) on its OWN segments
+    of 16 of the bench clouds -- the network's real, mixed segments, where matrix_rank -> ridge (fitting_utils.py:52-64), the cone
+    bail-out (primitive_forward.py:822-827) and the < 20-point skip (:974-978) fire. The oracle must take the same branch on every
+    segment and return the reference's parameters to 1e-4 rel (cylinder centre / radius: row a13's exception, checked on the device
+    side against the noise-free limit)."""
+    from fit64_common import BR_CONE_BAIL, BR_SKIPPED, TOL, compare_segment, reference_segments
+    from oracle import fit as of
+    from sednet_hip import synth
+    g, g64 = golden("f_64_fit"), golden("f_64")
+    worst, n_seg = {}, 0
+    for seed in [int(s) for s in g["seeds"]][::4]:
+        tag = f"s{seed}_"
+        p, n, _, _ = synth.synthetic_cloud(seed, 10000)
+        p, n = p.astype(np.float32), n.astype(np.float32)
+        canon, types, K = reference_segments(g, g64, seed)
+        st = g[tag + "seg_type"][:K]
+        for s in range(K):                                  # the type vote: stats.mode over the segment (residual_utils.py:259)
+            assert int(np.bincount(types[canon == s]).argmax()) == int(st[s])
+        ref = of.fit_segments_eval(p, n, canon, list(st))
+        for s in range(K):
+            br = int(g[tag + "branch"][s])
+            if ref[s] is None:
+                assert br == BR_SKIPPED, (seed, s)
+                continue
+            assert br != BR_SKIPPED, (seed, s)
+            q = np.zeros(7, np.float32)
+            vals = np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in ref[s][1:]])
+            q[:vals.shape[0]] = vals
+            is_bail = int(st[s]) == 3 and float(q[6]) == 0.0 and q[3:6].tolist() == [1.0, 0.0, 0.0]
+            assert is_bail == (br == BR_CONE_BAIL), (seed, s)
+            for k, v in compare_segment(int(st[s]), br, q, g[tag + "params"][s]).items():
+                worst[k] = max(worst.get(k, 0.0), v)
+            n_seg += 1
+    assert n_seg > 150 and max(worst.values()) < TOL, worst
+
+
 def test_cylinder_scatter_of_the_reference(golden):
     """F-CYL settles SURVEY row a13: fit_cylinder_torch (primitive_forward.py:788-810) sends a rank-2 system through
     the fp32 ridge branch of lstsq (fitting_utils.py:52-64, cond ~ 1e6). Its centre is rounding noise along the axis

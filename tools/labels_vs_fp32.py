@@ -36,8 +36,14 @@ print("| schedule | clouds with identical labels | clouds with the same cluster 
 print("|---|---:|---:|---:|---:|---:|")
 names = {"auto": "default (block-sparse, two weight digits)", "f16": "dense split-fp16, two weight digits", "sparse/1": "block-sparse, one weight digit",
          "f16/1": "dense split-fp16, one weight digit", "chunked": "exact fp32, key-chunked (another fp32 summation order)"}
+hist = {}
 for v, nm in names.items():
     a = [label_agreement(res[v][b], res["batched"][b]) for b in range(B)]
     mm = np.array([x_["mismatches"].size for x_ in a])
     same_n = sum(x_["n_got"] == x_["n_ref"] for x_ in a)
     print(f"| {nm} | {int((mm == 0).sum())} | {same_n} | {int(mm.sum())} | {int(mm.max())} | {int((mm > 10).sum())} |")
+    hist[nm] = np.array([x_["n_got"] - x_["n_ref"] for x_ in a])
+print()
+print("cluster count minus the exact fp32 kernel's, histogram over the clouds:")
+for nm, d in hist.items():
+    print(f"* {nm}: " + ", ".join(f"{int(k):+d}: {int((d == k).sum())}" for k in np.unique(d)))

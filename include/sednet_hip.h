@@ -62,6 +62,18 @@ int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* id
                       int* overflow, sed_stream_t stream);
 int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x6, int* idx, void* ws, size_t ws_bytes,
                          int* overflow, sed_stream_t stream);
+/* Round 6 (ABI 7): sed_knn_fused_f32 computed on an ORDERED copy of the rows. perm [B,N] int32 = a permutation of 0 .. N-1 per
+ * cloud (perm[b][j] = the row that takes position j; NULL = the caller's order). idx is bit-identical to sed_knn_fused_f32's for
+ * EVERY permutation (scores belong to (query, key) pairs, candidates keep their original index, ties go by it); a tile-coherent
+ * order (rows of a 32-row tile near each other) lets a wave dismiss the key tiles that hold none of its candidates with one
+ * comparison per lane. d = 64 / 128; other widths ignore perm.                         src/PointNet.py:62-87
+ * sed_spatial_order_f32: such an order from the network's INPUT x6 [B,6,N] (Morton order of the xyz + normal bounding box, 5 bits
+ * per channel; one workgroup per cloud; N <= sed_spatial_order_max_points() = 16384). A function of the cloud alone; shared by
+ * the feature layers and by the type / instance models of a step. Scheduling only: no reference counterpart. */
+int sed_knn_fused_order_f32(int B, int N, int d, int C, int k, const float* X, const int* perm, int* idx, void* ws,
+                            size_t ws_bytes, int* overflow, sed_stream_t stream);
+int sed_spatial_order_max_points(void);
+int sed_spatial_order_f32(int B, int N, const float* x6, int* perm, sed_stream_t stream);
 /* the k FARTHEST points per row (same selection on negated distances; farthest first, ties -> lowest index).
  * Replaces knn_idx (square_distance(...).topk(k), largest)            src/smooth_normal_matrix.py:33-40 */
 int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,

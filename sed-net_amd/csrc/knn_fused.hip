@@ -377,12 +377,15 @@ constexpr int SEL_MAXCHUNK = 4;                    // key chunks of sweep 2 at f
 // its start and b_p entries from its second half (the xyz-normal kernel packs everything into the first). The union has the
 // same members as the one-chunk lists (same threshold T), so the ranks -- hence the output -- do not depend on S; a union
 // beyond the 2 CAPL register slots raises the overflow flag like a full list does.
+// perm (round 6, may be null): the lists belong to row POSITIONS of an ordered cloud (knn_ordered.h); position j's neighbours are
+// written to output row perm[j] of its cloud (N rows per cloud).
 __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restrict__ lists, const int* __restrict__ counts,
                                                            int k, size_t rows, int S, int* __restrict__ idx_out,
-                                                           int* __restrict__ overflow) {
+                                                           int* __restrict__ overflow, const int* __restrict__ perm, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t row0 = ((size_t)blockIdx.x * 4 + wave) * FIN_ROWS;
     if (row0 >= rows) return;
+    auto out_row = [&](size_t row) { return perm ? row - row % (size_t)N + (size_t)perm[row] : row; };
     constexpr int NCH = (2 * CAPL + 63) / 64;
     int pa[FIN_ROWS][SEL_MAXCHUNK], pb[FIN_ROWS][SEL_MAXCHUNK], C[FIN_ROWS];
 #pragma unroll
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restric
             // fewer candidates than neighbours (rows with NaN features compare below no threshold): the row is handed to the exact
             // path like an overflowing one, and until then its unfilled slots hold a VALID index -- with deferred flags the graph is
             // consumed before the flag is read, and a stale word of the output buffer must never become a gather address
-            int* out_ = idx_out + (row0 + q) * k;
+            int* out_ = idx_out + out_row(row0 + q) * k;
             for (int e = Cq + lane; e < k; e += 64) out_[e] = 0;
             if (lane == 0) *overflow = 1;
         }
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restric
             for (int t2 = 0; t2 < NCH; ++t2)
                 if (Cq > 64 * t2) against_chunk(t2, std::integral_constant<int, NCH>{});
         }
-        int* out = idx_out + (row0 + q) * k;
+        int* out = idx_out + out_row(row0 + q) * k;
 #pragma unroll
         for (int t = 0; t < NCH; ++t)
             if (lane + 64 * t < Cq && rank[t] < k) out[rank[t]] = idx[q][t];
@@ -480,14 +483,57 @@ __global__ __launch_bounds__(256) void knn_finalize_kernel(const Cand* __restric
 
 int pick_M(int k) { return (3 * k + 63) / 64; }      // 32 M >= 1.5 k   (k = 20 -> 1, 32 -> 2, 64 -> 3, 85 -> 4)
 
+#include "knn_ordered.h"
+
+// the row image of an ORDERED cloud: image row j of a cloud = the split of its row perm[j] (same split: a function of the row
+// alone), xxo[j] = that row's squared norm (xx is computed in the caller's order first)
+template <int D>
+__global__ __launch_bounds__(256) void split_rows_perm_kernel(const float* __restrict__ X, const float* __restrict__ xx,
+                                                              const int* __restrict__ perm, int N, h16* __restrict__ img,
+                                                              float* __restrict__ inv, float* __restrict__ xxo, size_t rows) {
+    using Mp = SplitRowMap<D>;
+    constexpr int LPR = Mp::LPR, PER = Mp::PER;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = i / LPR;
+    const int j = (int)(i % LPR);
+    const size_t rc = row < rows ? row : rows - 1;
+    const size_t src = rc - rc % (size_t)N + (size_t)perm[rc];
+    f32x4 v[PER];
+    float am = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < rows) v[u] = *(const f32x4*)(X + src * D + 4 * (j + LPR * u));
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    const float scale = split_row_scale(am);
+    if (row >= rows) return;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        h16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h16 a, b; split_pair(v[u][e], scale, a, b); h[e] = a; l[e] = b; }
+        *(h16x4*)(img + row * 2 * D + 4 * (j + LPR * u)) = h;
+        *(h16x4*)(img + row * 2 * D + D + 4 * (j + LPR * u)) = l;
+    }
+    if (j == 0) { inv[row] = 1.0f / scale; xxo[row] = xx[src]; }
+}
+
 }  // namespace
 
+static inline size_t ord_blocks(int B, int N) { return (size_t)B * (((size_t)N + 127) / 128); }
+static inline size_t ord_tiles(int B, int N) { return (size_t)B * (((size_t)N + 31) / 32); }
 extern "C" size_t sed_knn_fused_workspace_bytes(int B, int N) {
     const size_t bn = (size_t)B * N;
     const size_t S = (size_t)sed_sel_chunks(B, N);
     return bn * sizeof(float) /*xx*/ + bn * sizeof(uint32_t) /*T*/ + bn * 2 * S * sizeof(int) /*counts*/ +
            bn * 2 * S * CAPL * sizeof(Cand) + 256 +
-           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image, d <= 128*/ + 256;
+           bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image, d <= 128*/ + 256 +
+           /* ordered form: xx in row order, sqrt of the tiles' largest xx, block lists + counts */
+           bn * sizeof(float) + 256 + ord_tiles(B, N) * sizeof(float) + 256 +
+           ord_blocks(B, N) * (((size_t)N + 31) / 32) * sizeof(unsigned short) + 256 + ord_blocks(B, N) * sizeof(int) + 256;
 }
 extern "C" int sed_knn_fused_max_k(void) { return 85; }
 
@@ -501,7 +547,7 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
                                     size_t ws_bytes, int* overflow, hipStream_t stream);
 
 namespace {
-struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; float* inv; h16* img; };
+struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; float* inv; h16* img; float* xxo; float* tsq; int* bcount; unsigned short* blist; };
 Ws carve(void* ws, int B, int N) {
     const size_t bn = (size_t)B * N;
     Ws w;
@@ -512,6 +558,10 @@ Ws carve(void* ws, int B, int N) {
     w.lists = (Cand*)(((uintptr_t)(w.counts + 2 * S * bn) + 15) & ~(uintptr_t)15);
     w.inv = (float*)(((uintptr_t)(w.lists + bn * 2 * S * CAPL) + 15) & ~(uintptr_t)15);
     w.img = (h16*)(((uintptr_t)(w.inv + bn) + 255) & ~(uintptr_t)255);
+    w.xxo = (float*)(((uintptr_t)(w.img + bn * 256) + 255) & ~(uintptr_t)255);
+    w.tsq = (float*)(((uintptr_t)(w.xxo + bn) + 255) & ~(uintptr_t)255);
+    w.bcount = (int*)(((uintptr_t)(w.tsq + ord_tiles(B, N)) + 255) & ~(uintptr_t)255);
+    w.blist = (unsigned short*)(((uintptr_t)(w.bcount + ord_blocks(B, N)) + 255) & ~(uintptr_t)255);
     return w;
 }
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows,
@@ -521,11 +571,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X
 }
 // d = 64 and d = 128 (the widths SED-Net uses) take the split-fp16 products; the row image is built once per call
 template <int NT, int M>
-void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, int far, hipStream_t s) {
+void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, int far, const int* perm, hipStream_t s) {
     constexpr bool F16 = NT == 2 || NT == 4;
-    if (F16) {
-        constexpr int D = F16 ? 32 * NT : 64;
+    if constexpr (F16) {
+        constexpr int D = 32 * NT;
         const size_t rows = (size_t)grid.y * N;
+        if (perm) {                      // ordered form (knn_ordered.h; the caller has checked its range)
+            const int ntiles = (N + 31) / 32;
+            const size_t tt = (size_t)grid.y * ntiles;
+            split_rows_perm_kernel<D><<<(unsigned)((rows * SplitRowMap<D>::LPR + 255) / 256), 256, 0, s>>>(X, w.xx, perm, N, w.img, w.inv,
+                                                                                                           w.xxo, rows);
+            ord_tilemax_kernel<<<(unsigned)((tt + 255) / 256), 256, 0, s>>>(w.xxo, N, ntiles, tt, w.tsq);
+            const float* Xi = (const float*)w.img;
+            knn_ord_bound_kernel<NT, M><<<grid, 256, 0, s>>>(Xi, w.xxo, w.inv, w.tsq, N, k, w.T, w.blist, w.bcount);
+            knn_ord_collect_kernel<NT><<<grid, 256, 0, s>>>(Xi, w.xxo, w.inv, N, w.T, w.lists, w.counts, overflow, perm, w.blist, w.bcount);
+            return;
+        }
         split_rows_launch<D>(X, w.img, w.inv, rows, s);
         X = (const float*)w.img;
     }
@@ -545,12 +606,12 @@ void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* ov
     }
 }
 template <int NT>
-int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, int far, hipStream_t s) {
+int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* overflow, int far, const int* perm, hipStream_t s) {
     switch (M) {
-        case 1: launch_sweeps<NT, 1>(grid, X, w, N, k, overflow, far, s); break;
-        case 2: launch_sweeps<NT, 2>(grid, X, w, N, k, overflow, far, s); break;
-        case 3: launch_sweeps<NT, 3>(grid, X, w, N, k, overflow, far, s); break;
-        case 4: launch_sweeps<NT, 4>(grid, X, w, N, k, overflow, far, s); break;
+        case 1: launch_sweeps<NT, 1>(grid, X, w, N, k, overflow, far, perm, s); break;
+        case 2: launch_sweeps<NT, 2>(grid, X, w, N, k, overflow, far, perm, s); break;
+        case 3: launch_sweeps<NT, 3>(grid, X, w, N, k, overflow, far, perm, s); break;
+        case 4: launch_sweeps<NT, 4>(grid, X, w, N, k, overflow, far, perm, s); break;
         default: return SED_EUNSUPPORTED;
     }
     return SED_OK;
@@ -558,22 +619,31 @@ int launch_nt(dim3 grid, int M, const float* X, const Ws& w, int N, int k, int* 
 }  // namespace
 
 static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
-                          int* overflow, int far, hipStream_t stream);
+                          int* overflow, int far, const int* perm, hipStream_t stream);
 
 extern "C" int sed_knn_fused_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
                                  size_t ws_bytes, int* overflow, hipStream_t stream) {
-    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 0, stream);
+    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 0, nullptr, stream);
+}
+
+// The same graph computed on an ORDERED copy of the rows (knn_ordered.h): perm [B,N] int32 (a permutation of 0 .. N-1 per cloud,
+// e.g. sed_spatial_order_f32 of the network's input; null = the caller's order). idx is bit-identical to sed_knn_fused_f32's for
+// every permutation -- a tile-coherent order only decides how many key tiles a wave can dismiss early. The ordered form runs at
+// d = 64 / 128, N <= 16384, for calls large enough to fill the chip with one key chunk; anything else ignores perm.
+extern "C" int sed_knn_fused_order_f32(int B, int N, int d, int C, int k, const float* X, const int* perm, int* idx, void* ws,
+                                       size_t ws_bytes, int* overflow, hipStream_t stream) {
+    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 0, perm, stream);
 }
 
 // Same selection on the NEGATED distances: idx [B,N,k] = the k FARTHEST points of every row, farthest first (ties ->
 // lowest index). Replaces knn_idx of src/smooth_normal_matrix.py:33-40 (square_distance(...).topk(k) -- largest).
 extern "C" int sed_knn_fused_far_f32(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws,
                                      size_t ws_bytes, int* overflow, hipStream_t stream) {
-    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 1, stream);
+    return knn_fused_impl(B, N, d, C, k, X, idx, ws, ws_bytes, overflow, 1, nullptr, stream);
 }
 
 static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int* idx, void* ws, size_t ws_bytes,
-                          int* overflow, int far, hipStream_t stream) {
+                          int* overflow, int far, const int* perm, hipStream_t stream) {
     if (B <= 0 || N <= 0 || k <= 0 || k > N || !X || !idx || !ws || !overflow || C > d) return SED_EINVAL;
     if (d % 32 != 0 || d < 32 || d > 128 || k > 85) return SED_EUNSUPPORTED;
     if (ws_bytes < sed_knn_fused_workspace_bytes(B, N)) return SED_EINVAL;
@@ -585,17 +655,20 @@ static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int
     SED_LAUNCH_CHECK();
     dim3 grid((N + 127) / 128, B);
     const int M = pick_M(k);
+    // the ordered form: nearest neighbours at the split-fp16 widths, one key chunk, tile maps of <= 512 tiles
+    if (!(perm && !far && (d == 64 || d == 128) && sed_sel_chunks(B, N) == 1 && N <= 32 * ORD_MAXTILES)) perm = nullptr;
     int rc;
     switch (d / 32) {
-        case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, far, stream); break;
-        case 2: rc = launch_nt<2>(grid, M, X, w, N, k, overflow, far, stream); break;
-        case 3: rc = launch_nt<3>(grid, M, X, w, N, k, overflow, far, stream); break;
-        default: rc = launch_nt<4>(grid, M, X, w, N, k, overflow, far, stream); break;
+        case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, far, perm, stream); break;
+        case 2: rc = launch_nt<2>(grid, M, X, w, N, k, overflow, far, perm, stream); break;
+        case 3: rc = launch_nt<3>(grid, M, X, w, N, k, overflow, far, perm, stream); break;
+        default: rc = launch_nt<4>(grid, M, X, w, N, k, overflow, far, perm, stream); break;
     }
     if (rc != SED_OK) return rc;
     SED_LAUNCH_CHECK();
     knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, (size_t)rows,
-                                                                                                  sed_sel_chunks(B, N), idx, overflow);
+                                                                                                  sed_sel_chunks(B, N), idx, overflow,
+                                                                                                  perm, N);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }
@@ -631,7 +704,8 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
     SED_LAUNCH_CHECK();
     const size_t rows = (size_t)B * N;
     knn_finalize_kernel<<<(unsigned)((rows + 4 * FIN_ROWS - 1) / (4 * FIN_ROWS)), 256, 0, stream>>>(w.lists, w.counts, k, rows,
-                                                                                                  sed_sel_chunks(B, N), idx, overflow);
+                                                                                                  sed_sel_chunks(B, N), idx, overflow,
+                                                                                                  nullptr, N);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -37,6 +37,9 @@ SIGNATURES = {
     "sed_knn_fused_max_k": (c_int, []),
     "sed_knn_fused_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_knn_pn_fused_f32": (c_int, [c_int, c_int, c_int, c_float, P, P, P, c_size_t, P, P]),
+    "sed_knn_fused_order_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P, P]),
+    "sed_spatial_order_max_points": (c_int, []),
+    "sed_spatial_order_f32": (c_int, [c_int, c_int, P, P, P]),
     "sed_knn_fused_far_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P, P]),
     "sed_csr_spmm_f32": (c_int, [c_int, c_int, c_int, c_size_t, P, P, P, P, c_int, P, c_int, P]),
     "sed_hpnet_affinity_csr_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

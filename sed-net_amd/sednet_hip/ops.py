@@ -69,16 +69,38 @@ def _fused_ws(B, N, device):
     return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
 
 
-def knn_features(X, k, C=None):
+KNN_ORDER = True        # feature-space kNN sweeps on a Morton order of the input cloud (round 6; neighbours do not depend on it)
+
+
+def spatial_order(x6):
+    """x6 [B,6,N] channel-major -> perm [B,N] int32, the Morton order of every cloud's (xyz, normal) bounding box, or None when the
+    ordered sweeps are off / the cloud is larger than the sort's range. A scheduling aid of knn_features (no reference counterpart):
+    any permutation gives the same neighbours."""
+    B, _, N = x6.shape
+    if not (KNN_ORDER and FUSED_KNN) or N > lib.sed_spatial_order_max_points() or N < 256:
+        return None
+    x6 = x6.contiguous().float()
+    perm = torch.empty((B, N), dtype=torch.int32, device=x6.device)
+    check(lib.sed_spatial_order_f32(B, N, ptr(x6), ptr(perm), stream()), "spatial_order")
+    return perm
+
+
+def knn_features(X, k, C=None, order=None):
     """kNN graph on point-major features X [B,N,D] (first C channels real) -> idx [B,N,k] int32,
-    nearest first, self included (src/PointNet.py:62-87)."""
+    nearest first, self included (src/PointNet.py:62-87). order: optional spatial_order(...) of the same clouds (speed only)."""
     B, N, D = X.shape
     C = D if C is None else C
     idx = torch.empty((B, N, k), dtype=torch.int32, device=X.device)
     if FUSED_KNN and k <= 85 and D <= 128 and N >= 32:
         ws, nbytes = _fused_ws(B, N, X.device)
         flag = torch.empty((1,), dtype=torch.int32, device=X.device)
-        check(lib.sed_knn_fused_f32(B, N, D, C, k, ptr(X), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()), "knn_fused")
+        if order is not None:
+            if order.shape != (B, N) or order.dtype != torch.int32 or not order.is_contiguous():
+                raise ValueError("order must be a contiguous int32 [B,N] permutation per cloud")
+            check(lib.sed_knn_fused_order_f32(B, N, D, C, k, ptr(X), ptr(order), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()),
+                  "knn_fused_order")
+        else:
+            check(lib.sed_knn_fused_f32(B, N, D, C, k, ptr(X), ptr(idx), ptr(ws), nbytes, ptr(flag), stream()), "knn_fused")
         if DEFERRED_KNN_FLAGS is not None:
             DEFERRED_KNN_FLAGS.append(flag)
             return idx

@@ -82,6 +82,7 @@ class SegmentationPipeline:
             # the first-layer kNN graph depends only on the cloud: computed once for both models when they agree on (k, W)
             e0, e1 = self.model_type.encoder, self.model_inst.encoder
             idx1 = e0.input_graph(x6) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+            order = e0.input_order(x6)                      # row order of the feature-space kNN sweeps: a function of the cloud alone
             if ev is not None:
                 ev.mark("input_graph")
             if x6.shape[0] <= self.TWO_STREAM_MAX_CLOUDS:
@@ -95,9 +96,9 @@ class SegmentationPipeline:
                     self._side = torch.cuda.Stream()
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
-                    _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
+                    _, log_prob, _ = self.model_type.forward_point_major(x6, idx1, order)
                     t_model = ops.row_argmax(log_prob, log_prob.shape[2])
-                emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
+                emb, _, edges = self.model_inst.forward_point_major(x6, idx1, order)
                 X = ops.row_normalize(emb, emb.shape[2])
                 main.wait_stream(self._side)
                 log_prob.record_stream(main)
@@ -105,11 +106,11 @@ class SegmentationPipeline:
                 if ev is not None:
                     ev.mark("type_model")
             else:
-                _, log_prob, _ = self.model_type.forward_point_major(x6, idx1)
+                _, log_prob, _ = self.model_type.forward_point_major(x6, idx1, order)
                 t_model = ops.row_argmax(log_prob, log_prob.shape[2])
                 if ev is not None:
                     ev.mark("type_model")
-                emb, _, edges = self.model_inst.forward_point_major(x6, idx1)
+                emb, _, edges = self.model_inst.forward_point_major(x6, idx1, order)
                 X = ops.row_normalize(emb, emb.shape[2])
         finally:
             ops.DEFERRED_KNN_FLAGS = prev
@@ -145,11 +146,12 @@ class SegmentationPipeline:
                     cap = torch.cuda.current_stream()
                     e0, e1 = self.model_type.encoder, self.model_inst.encoder
                     idx1 = e0.input_graph(static_x) if (e0.k == e1.k and e0.normal_metric_W == e1.normal_metric_W) else None
+                    order = e0.input_order(static_x)
                     self._side.wait_stream(cap)
                     with torch.cuda.stream(self._side):
-                        _, log_prob, _ = self.model_type.forward_point_major(static_x, idx1)
+                        _, log_prob, _ = self.model_type.forward_point_major(static_x, idx1, order)
                         t_model = ops.row_argmax(log_prob, log_prob.shape[2])
-                    emb, _, edges = self.model_inst.forward_point_major(static_x, idx1)
+                    emb, _, edges = self.model_inst.forward_point_major(static_x, idx1, order)
                     X = ops.row_normalize(emb, emb.shape[2])
                     cap.wait_stream(self._side)
             finally:

@@ -105,9 +105,15 @@ class DGCNNEncoderGn(nn.Module):
         share k and normal_metric_W -- the type and instance models of the driver -- can share it."""
         return ops.knn_points_normals(x.detach().float().contiguous(), self.k, self.normal_metric_W)
 
-    def forward_point_major(self, x, idx1=None, feats_bound=None):
+    def input_order(self, x):
+        """Morton order of the input cloud for the feature-space kNN sweeps (ops.spatial_order): like the input graph it depends on
+        the cloud alone, so the two models of the driver share it. Speed only: the graphs do not depend on it."""
+        return ops.spatial_order(x.detach().float().contiguous())
+
+    def forward_point_major(self, x, idx1=None, feats_bound=None, order=None):
         """x [B,6,N] -> (x4 [B,1024], feats [B,N,256] point-major). idx1: optional precomputed input_graph(x).
-        feats_bound: optional ops.row_bounds(B, N) that receives max |feats| per row (for the split-fp16 layers on feats)."""
+        feats_bound: optional ops.row_bounds(B, N) that receives max |feats| per row (for the split-fp16 layers on feats).
+        order: optional precomputed input_order(x)."""
         if self.mode != 5 or self.input_channels != 6:
             raise NotImplementedError("the HIP path implements mode 5 with xyz+normal input (the SED-Net configuration)")
         B, _, N = x.shape
@@ -122,13 +128,15 @@ class DGCNNEncoderGn(nn.Module):
         # ties); `keep_graphs` = True records the graphs of this forward in `last_graphs`
         gin = self.graphs_in
         idx = (ops.knn_points_normals(x, k, self.normal_metric_W) if idx1 is None else idx1) if gin is None else gin[0]
+        if order is None and gin is None:
+            order = ops.spatial_order(x)
         x1 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
         fb = feats_bound if feats_bound is not None else ops.row_bounds(B, N, dev)
         self._edge("e1", x8, 6, idx, (x1, feats[:, :, 0:64]), rowmax=fb)
-        idx2 = ops.knn_features(x1, k, 64) if gin is None else gin[1]
+        idx2 = ops.knn_features(x1, k, 64, order=order) if gin is None else gin[1]
         x2 = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
         self._edge("e2", x1, 64, idx2, (x2, feats[:, :, 64:128]), rowmax=fb)
-        idx3 = ops.knn_features(x2, k, 64) if gin is None else gin[2]
+        idx3 = ops.knn_features(x2, k, 64, order=order) if gin is None else gin[2]
         self._edge("e3", x2, 64, idx3, (feats[:, :, 128:256],), rowmax=fb)
         if self.keep_graphs:
             self.last_graphs = (idx, idx2, idx3)
@@ -264,10 +272,11 @@ class SEDNet(nn.Module):
         gamma, beta = c[bn_key]
         return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend, rowmax=y_bound)
 
-    def forward_point_major(self, points, idx1=None):
+    def forward_point_major(self, points, idx1=None, order=None):
         """points [B,6,N] -> (embedding [B,N,emb], log_prob [B,N,P], edges [B,N,2]) point-major device tensors
         (views into kernel output buffers). This is what the batched driver consumes: no transposes.
-        idx1: optional first-layer graph from encoder.input_graph(points) (shared between models)."""
+        idx1: optional first-layer graph from encoder.input_graph(points) (shared between models);
+        order: optional encoder.input_order(points) (likewise; speed only)."""
         if not (self.primitives and self.embedding and self.edge_module is not None and self.combine_label_prim
                 and self.late_fusion):
             raise NotImplementedError("the HIP path implements the configuration used by the SED-Net scripts "
@@ -278,7 +287,7 @@ class SEDNet(nn.Module):
             dev = points.device
             # per-row magnitude bounds of the GroupNorm outputs: what lets the next layer run in the two-plane split-fp16 form
             bnd = [ops.row_bounds(B, N, dev) for _ in range(5)]
-            x4, feats = self.encoder.forward_point_major(points, idx1, feats_bound=bnd[0])
+            x4, feats = self.encoder.forward_point_major(points, idx1, feats_bound=bnd[0], order=order)
             # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
             cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
             a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"],

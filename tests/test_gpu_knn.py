@@ -232,3 +232,67 @@ def test_first_layer_graph_on_odd_cloud_sizes_equals_the_materialised_path(T, N)
         finally:
             ops.FUSED_KNN = True
         np.testing.assert_array_equal(fused, exact)
+
+
+def test_spatial_order_is_a_permutation_and_a_function_of_the_cloud(T):
+    """ops.spatial_order (round 6, spatial_order.hip): a permutation of 0 .. N-1 for every cloud -- also with non-finite and
+    constant channels --, the same for a cloud whatever batch it comes in, Morton codes non-decreasing along it."""
+    from sednet_hip import ops, synth
+    for N in (10000, 4099, 300):
+        x = synth.batch_clouds(3, N, seed0=5)[0]
+        x[1, 3] = 0.25                                            # a constant channel (zero extent)
+        x[2, 0, 5] = np.nan
+        x[2, 4, 7] = np.inf
+        xd = dev(T, x)
+        perm = ops.spatial_order(xd)
+        assert perm.dtype == T.int32 and tuple(perm.shape) == (3, N)
+        p = perm.cpu().numpy()
+        for b in range(3):
+            np.testing.assert_array_equal(np.sort(p[b]), np.arange(N))
+        assert T.equal(ops.spatial_order(xd[1:2].contiguous()), perm[1:2])
+        # the code of cloud 0, recomputed on the host
+        c = x[0].T.astype(np.float32)
+        lo, hi = c.min(0), c.max(0)
+        q = np.clip(((c - lo) * (np.float32(32.0) / (hi - lo))).astype(np.float32), 0, 31).astype(np.int64)
+        code = np.zeros(N, np.int64)
+        for ch in range(6):
+            for bit in range(5):
+                code |= ((q[:, ch] >> bit) & 1) << (6 * bit + ch)
+        cs = code[p[0]]
+        assert (np.diff(cs) >= 0).all()
+        assert (np.diff(p[0])[np.diff(cs) == 0] > 0).all()       # equal codes: by index
+    assert ops.spatial_order(dev(T, synth.batch_clouds(1, 128, seed0=5)[0])) is None          # below the ordered sweeps' range
+
+
+@pytest.mark.parametrize("k", [20, 64])
+def test_ordered_sweeps_return_the_same_graph_for_every_order(T, k):
+    """sed_knn_fused_order_f32 (round 6): the feature-space graph computed on an ordered copy of the rows is BIT-IDENTICAL to the
+    unordered one for every permutation -- the Morton order of an input cloud, a random permutation, the reversed order -- on
+    unstructured features (every key tile holds candidates), on features that follow the cloud's geometry (most key tiles are
+    dismissed by the one-comparison test), with duplicated rows (ties go by the ORIGINAL index), on a ragged N, at d = 64 and
+    d = 128, alone (key-chunked second sweep) and in a batch."""
+    from sednet_hip import ops, synth
+    rng = np.random.default_rng(100 + k)
+    for N, B in ((10000, 3), (4099, 2), (1000, 5)):
+        x6 = synth.batch_clouds(B, N, seed0=31)[0]
+        geo = np.concatenate([x6, x6[:, :3] * x6[:, 3:]], 1).transpose(0, 2, 1)              # [B,N,9]: smooth functions of the cloud
+        for d in (64, 128):
+            W = rng.normal(size=(9, d)).astype(np.float32)
+            F_geo = np.tanh(geo @ W).astype(np.float32) + 1e-3 * rng.normal(size=(B, N, d)).astype(np.float32)
+            F_rand = rng.normal(size=(B, N, d)).astype(np.float32)
+            for F in (F_geo, F_rand):
+                F[:, 17] = F[:, 3]
+                F[0, 200:230] = F[0, 200]                          # 30 equal rows: more ties than k = 20 can take
+                Fd = dev(T, F)
+                ref = ops.knn_features(Fd, k, d)
+                morton = ops.spatial_order(dev(T, x6))
+                orders = [T.from_numpy(np.stack([rng.permutation(N) for _ in range(B)]).astype(np.int32)).cuda(),
+                          T.arange(N - 1, -1, -1, dtype=T.int32, device="cuda").repeat(B, 1).contiguous()]
+                if morton is not None:
+                    orders.append(morton)
+                for o in orders:
+                    got = ops.knn_features(Fd, k, d, order=o)
+                    assert T.equal(got, ref), (N, d, int((got != ref).any(2).sum()))
+                if morton is not None:
+                    one = ops.knn_features(Fd[:1].contiguous(), k, d, order=morton[:1].contiguous())
+                    assert T.equal(one, ref[:1])

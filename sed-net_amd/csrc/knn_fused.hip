@@ -533,7 +533,7 @@ extern "C" size_t sed_knn_fused_workspace_bytes(int B, int N) {
            bn * sizeof(float) /*row scales*/ + bn * 128 * sizeof(float) /*split-fp16 row image, d <= 128*/ + 256 +
            /* ordered form: xx in row order, sqrt of the tiles' largest xx, block lists + counts */
            bn * sizeof(float) + 256 + ord_tiles(B, N) * sizeof(float) + 256 +
-           ord_blocks(B, N) * (((size_t)N + 31) / 32) * sizeof(unsigned short) + 256 + ord_blocks(B, N) * sizeof(int) + 256;
+           ord_blocks(B, N) * (((size_t)N + 31) / 32) * sizeof(uint32_t) + 256 + ord_blocks(B, N) * sizeof(int) + 256;
 }
 extern "C" int sed_knn_fused_max_k(void) { return 85; }
 
@@ -547,7 +547,7 @@ extern "C" int sed_knn_pn_fused_f32(int B, int N, int k, float W, const float* x
                                     size_t ws_bytes, int* overflow, hipStream_t stream);
 
 namespace {
-struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; float* inv; h16* img; float* xxo; float* tsq; int* bcount; unsigned short* blist; };
+struct Ws { float* xx; uint32_t* T; int* counts; Cand* lists; float* inv; h16* img; float* xxo; float* tsq; int* bcount; uint32_t* blist; };
 Ws carve(void* ws, int B, int N) {
     const size_t bn = (size_t)B * N;
     Ws w;
@@ -561,7 +561,7 @@ Ws carve(void* ws, int B, int N) {
     w.xxo = (float*)(((uintptr_t)(w.img + bn * 256) + 255) & ~(uintptr_t)255);
     w.tsq = (float*)(((uintptr_t)(w.xxo + bn) + 255) & ~(uintptr_t)255);
     w.bcount = (int*)(((uintptr_t)(w.tsq + ord_tiles(B, N)) + 255) & ~(uintptr_t)255);
-    w.blist = (unsigned short*)(((uintptr_t)(w.bcount + ord_blocks(B, N)) + 255) & ~(uintptr_t)255);
+    w.blist = (uint32_t*)(((uintptr_t)(w.bcount + ord_blocks(B, N)) + 255) & ~(uintptr_t)255);
     return w;
 }
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X, float* __restrict__ xx, int rows,
@@ -570,21 +570,38 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ X
     sed_row_sqnorm_block(X, xx, rows, D, C, tile);
 }
 // d = 64 and d = 128 (the widths SED-Net uses) take the split-fp16 products; the row image is built once per call
+// the ordered kernels' tile rings are dynamic LDS (d = 128: 66 KiB + the tile maps, beyond the default limit)
+template <int NT, int M>
+int ord_raise_lds_limit() {
+    static std::atomic<unsigned long long> attr{0};          // devices whose limit has been raised (common.h)
+    int attr_err = 0;
+    if (sed_first_on_device(attr, &attr_err)) {
+        constexpr int SM = OrdRing<NT>::NBUF * OrdRing<NT>::IMG + 4 * (ORD_MAXTILES / 32) * 4 + 64;
+        hipError_t e = hipFuncSetAttribute((const void*)knn_ord_bound_kernel<NT, M>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)knn_ord_collect_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+        if (e != hipSuccess) return (int)e;
+        sed_mark_device(attr);
+    } else if (attr_err) return attr_err;
+    return 0;
+}
+
 template <int NT, int M>
 void launch_sweeps(dim3 grid, const float* X, const Ws& w, int N, int k, int* overflow, int far, const int* perm, hipStream_t s) {
     constexpr bool F16 = NT == 2 || NT == 4;
     if constexpr (F16) {
         constexpr int D = 32 * NT;
         const size_t rows = (size_t)grid.y * N;
-        if (perm) {                      // ordered form (knn_ordered.h; the caller has checked its range)
+        if (perm && ord_raise_lds_limit<NT, M>() == 0) {      // ordered form (knn_ordered.h; the caller has checked its range)
             const int ntiles = (N + 31) / 32;
             const size_t tt = (size_t)grid.y * ntiles;
             split_rows_perm_kernel<D><<<(unsigned)((rows * SplitRowMap<D>::LPR + 255) / 256), 256, 0, s>>>(X, w.xx, perm, N, w.img, w.inv,
                                                                                                            w.xxo, rows);
             ord_tilemax_kernel<<<(unsigned)((tt + 255) / 256), 256, 0, s>>>(w.xxo, N, ntiles, tt, w.tsq);
             const float* Xi = (const float*)w.img;
-            knn_ord_bound_kernel<NT, M><<<grid, 256, 0, s>>>(Xi, w.xxo, w.inv, w.tsq, N, k, w.T, w.blist, w.bcount);
-            knn_ord_collect_kernel<NT><<<grid, 256, 0, s>>>(Xi, w.xxo, w.inv, N, w.T, w.lists, w.counts, overflow, perm, w.blist, w.bcount);
+            constexpr int SM_C = OrdRing<NT>::NBUF * OrdRing<NT>::IMG, SM_B = SM_C + 4 * (ORD_MAXTILES / 32) * 4 + 64;
+            knn_ord_bound_kernel<NT, M><<<grid, 256, SM_B, s>>>(Xi, w.xxo, w.inv, w.tsq, perm, N, k, w.T, w.blist, w.bcount);
+            knn_ord_collect_kernel<NT><<<grid, 256, SM_C, s>>>(Xi, w.xxo, w.inv, N, w.T, w.lists, w.counts, overflow, perm, w.blist, w.bcount);
             return;
         }
         split_rows_launch<D>(X, w.img, w.inv, rows, s);

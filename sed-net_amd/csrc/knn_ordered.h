@@ -47,35 +47,85 @@ __global__ __launch_bounds__(256) void ord_tilemax_kernel(const float* __restric
     tsq[i] = bad ? __builtin_inff() : sqrtf(m);                 // a non-finite row: the tile is never dismissed
 }
 
-// shared by the two sweeps: stage one 32-row tile of the row image (+ the rows' squared norms and 2^-e) through registers
+// shared by the two sweeps: key tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave
+// instruction, no staging registers) into a ring of NBUF tile images, three tiles ahead of the one being scored -- with one tile
+// of look-ahead through registers the bound sweep's loop was waiting for L2 (0.94 of its 2.5 ms with all arithmetic removed).
+// Tile image: 32 rows x (h plane | l plane) = 32 x 4 D bytes in 16-byte chunks, chunk j of row r at slot (j & ~15) | ((j ^ r) & 15)
+// of its row -- the 16 lanes that a ds_read_b128 serves together read 16 different rows at the same j, the XOR sends them to 16
+// different bank groups --, then the rows' squared norms [32], 2^-e [32] and original indices [32]. A lane's DMA source address is free, so the swizzle
+// costs nothing on the way in. Rows beyond N repeat row N - 1 (the element tests exclude them by index).
+// The copies are inline instructions the compiler does not track (it would wait for ALL of them before every LDS read): a tile is
+// waited for explicitly -- every wave issues PW copies per tile, in order, so "at most 2 PW outstanding" = the tile three back has
+// landed -- and published by the loop's one barrier, which also says that everyone has finished the tile whose slot is refilled next.
 template <int NT>
-struct OrdTile {
-    static constexpr int D = 32 * NT, LDX = D + 4, C4 = D / 4;
-    f32x4 v[NT];
-    float sxx, sck;
-    __device__ __forceinline__ void load(const float* Xc, const float* xxc, const float* invc, int N, int tile, int tid) {
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int i = tid + 256 * u;
-            const int row = i / C4, c4 = i % C4;
-            const int key = tile * 32 + row;
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (key < N) v[u] = *(const f32x4*)(Xc + (size_t)key * D + 4 * c4);
-        }
-        if (tid < 32) {
-            const int key = tile * 32 + tid;
-            sxx = key < N ? xxc[key] : 0.f;
-            sck = key < N ? invc[key] : 0.f;
-        }
+struct OrdRing {
+    static constexpr int D = 32 * NT, ROWB = 4 * D, CPR = ROWB / 16, IMG = 32 * ROWB + 512, NBUF = 4;
+    static constexpr int PIECES = 32 * ROWB / 1024, PW = PIECES / 4 + 2;          // per wave and tile: its share of the planes, xx | 2^-e, perm
+    static_assert(PIECES % 4 == 0, "plane pieces per wave");
+    static __device__ __forceinline__ void dma16(const void* g, const uint8_t* l) {
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const uint8_t*)l);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
     }
-    __device__ __forceinline__ void store(float* lds, float* xxs, float* cks, int tid) const {
+    static __device__ __forceinline__ void dma4(const void* g, const uint8_t* l) {
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const uint8_t*)l);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(la) : "memory");
+    }
+    // issue this wave's copies of key tile `tile` into ring slot `buf`
+    static __device__ __forceinline__ void issue(uint8_t* ring, int buf, const float* Xc, const float* xxc, const float* invc,
+                                                 const int* permc, int N, int tile, int wave, int lane) {
+        uint8_t* img = ring + buf * IMG;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int i = tid + 256 * u;
-            const int row = i / C4, c4 = i % C4;
-            *(f32x4*)(&lds[row * LDX + 4 * c4]) = v[u];
+        for (int u = 0; u < PIECES / 4; ++u) {
+            const int piece = wave * (PIECES / 4) + u;
+            const int q = piece * 64 + lane;                        // chunk slot of the image
+            const int row = q / CPR, slot = q % CPR;
+            const int j = (slot & ~15) | ((slot ^ row) & 15);
+            const int key = tile * 32 + row < N ? tile * 32 + row : N - 1;
+            dma16((const uint8_t*)Xc + (size_t)key * ROWB + j * 16, img + piece * 1024);
         }
-        if (tid < 32) { xxs[tid] = sxx; cks[tid] = sck; }
+        const int r = lane & 31;
+        const int key = tile * 32 + r < N ? tile * 32 + r : N - 1;
+        dma4(lane < 32 ? xxc + key : invc + key, img + 32 * ROWB);
+        dma4(permc + key, img + 32 * ROWB + 256);                  // (both halves of the wave write the same 32 words twice)
+    }
+    template <int AHEAD>                                            // AHEAD = tiles issued after the one needed now (0 .. 2)
+    static __device__ __forceinline__ void wait_publish() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AHEAD * PW) : "memory");
+    }
+    static __device__ __forceinline__ void wait_publish(int ahead) {
+        if (ahead >= 2) wait_publish<2>();
+        else if (ahead == 1) wait_publish<1>();
+        else wait_publish<0>();
+    }
+    static __device__ __forceinline__ h16x8 chunk(const uint8_t* img, int row, int j) {
+        return *(const h16x8*)(img + row * ROWB + (((j & ~15) | ((j ^ row) & 15)) << 4));
+    }
+    static __device__ __forceinline__ const float* xxs(const uint8_t* img) { return (const float*)(img + 32 * ROWB); }
+    static __device__ __forceinline__ const float* cks(const uint8_t* img) { return (const float*)(img + 32 * ROWB + 128); }
+    static __device__ __forceinline__ const int* perms(const uint8_t* img) { return (const int*)(img + 32 * ROWB + 256); }
+    // head product only (1 of the 3 MFMAs per 16 features)
+    static __device__ __forceinline__ f32x16 head(const uint8_t* img, int li, int hi, const h16x8* qh) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) s = mfma16(chunk(img, li, 2 * ks + hi), qh[ks], s);
+        return s;
+    }
+    // the split-fp16 product of split16.h::split_tile_keys_on_rows, same instruction order => the same bits
+    static __device__ __forceinline__ f32x16 exact(const uint8_t* img, int li, int hi, const h16x8* qh, const h16x8* ql) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) {
+            const h16x8 xh = chunk(img, li, 2 * ks + hi);
+            const h16x8 xl = chunk(img, li, CPR / 2 + 2 * ks + hi);
+            s = mfma16(xl, qh[ks], s);
+            s = mfma16(xh, ql[ks], s);
+            s = mfma16(xh, qh[ks], s);
+        }
+        return s;
     }
 };
 
@@ -106,18 +156,22 @@ __device__ __forceinline__ float ord_reach(float xq, float bound) {
     return bound < __builtin_inff() ? (xq - bound) - 1.0e-6f * (fabsf(xq) + fabsf(bound)) : -__builtin_inff();
 }
 
+// The compiler waits for a load where its value is first used -- for the query planes that is inside the tile loop, and there a
+// wait for "my loads" (it does not know about the copies in flight) is a wait for every copy: the ring would never run ahead.
+// An empty asm that takes the value as an operand puts that wait in front of the loop.
+#define ORD_SETTLE(x) asm volatile("" : "+v"(x))
+
 template <int NT, int M>
 __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __restrict__ X, const float* __restrict__ xx,
                                                                const float* __restrict__ inv, const float* __restrict__ tsq,
-                                                               int N, int k, uint32_t* __restrict__ Tbuf,
-                                                               unsigned short* __restrict__ blist, int* __restrict__ bcount) {
-    using St = OrdTile<NT>;
-    constexpr int D = St::D, LDX = St::LDX;
-    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
-    __shared__ __attribute__((aligned(16))) float xxs[2][32];
-    __shared__ __attribute__((aligned(16))) float cks[2][32];
-    __shared__ uint32_t fl[4][ORD_MAXTILES / 32];
-    __shared__ int wsum[4];
+                                                               const int* __restrict__ perm, int N, int k,
+                                                               uint32_t* __restrict__ Tbuf, uint32_t* __restrict__ blist,
+                                                               int* __restrict__ bcount) {
+    using Rg = OrdRing<NT>;
+    constexpr int D = Rg::D;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];          // Rg::NBUF tile images | tile maps | wave sums
+    uint32_t (*fl)[ORD_MAXTILES / 32] = (uint32_t (*)[ORD_MAXTILES / 32])(ring + Rg::NBUF * Rg::IMG);
+    int* wsum = (int*)(ring + Rg::NBUF * Rg::IMG + 4 * (ORD_MAXTILES / 32) * 4);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     int bxi;
@@ -127,18 +181,22 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
     const float* invc = inv + (size_t)cloud * N;
     const int ntiles = (N + 31) >> 5;
     const float* tsqc = tsq + (size_t)cloud * ntiles;
+    const int* permc = perm + (size_t)cloud * N;
     const int qrow = bxi * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     for (int i = tid; i < 4 * (ORD_MAXTILES / 32); i += 256) (&fl[0][0])[i] = 0u;
 
     h16x8 qh[2 * NT], ql[2 * NT];
     split_load_query<NT>((const h16*)Xc + (size_t)qrow_c * 2 * D, hi, qh, ql);
-    const float two_cq = 2.0f * invc[qrow_c];
-    const float xq = xxc[qrow_c];
+    float two_cq = 2.0f * invc[qrow_c];
+    float xq = xxc[qrow_c];
     // margin of the head product: the dropped terms l.h + h.l + l.l are <= 2^-10 (1 + 2^-10) |x_i||x_j| per dot product (|l| <=
     // 2^-11 |h| element by element, Cauchy-Schwarz), twice that in 2 x_i.x_j; 5 % on top covers the accumulation roundings of
     // both products and of xx (each ~1e-6 of the same magnitude)
-    const float emul = 1.05f * 0.001953125f * sqrtf(xq);
+    float emul = 1.05f * 0.001953125f * sqrtf(xq);
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) { ORD_SETTLE(qh[ks]); ORD_SETTLE(ql[ks]); }
+    ORD_SETTLE(two_cq); ORD_SETTLE(xq); ORD_SETTLE(emul);
 
     float bm[M][16];                                            // the M largest t = 2 x_i.x_j - xx_j per bucket (see knn_sweep_kernel)
 #pragma unroll
@@ -169,30 +227,24 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
     const int own0 = 4 * bxi, nown = ntiles - own0 < 4 ? ntiles - own0 : 4;
     auto tile_at = [&](int i) { return i < nown ? own0 + i : (i - nown < own0 ? i - nown : i); };
     float Rthr = -__builtin_inff();
-    St st;
-    st.load(Xc, xxc, invc, N, tile_at(0), tid);
-    st.store(lds[0], xxs[0], cks[0], tid);
-    __syncthreads();
-    int cur = 0;
+    __syncthreads();                                            // fl is zero; nothing else has touched LDS
+    for (int p = 0; p < 3 && p < ntiles; ++p) Rg::issue(ring, p, Xc, xxc, invc, permc, N, tile_at(p), wave, lane);
     for (int vi = 0; vi < ntiles; ++vi) {
         const int tile = tile_at(vi);
-        if (vi + 1 < ntiles) st.load(Xc, xxc, invc, N, tile_at(vi + 1), tid);
-        const uint8_t* krow = (const uint8_t*)(lds[cur] + li * LDX);
+        Rg::wait_publish(ntiles - 1 - vi);
+        if (vi + 3 < ntiles) Rg::issue(ring, (vi + 3) & 3, Xc, xxc, invc, permc, N, tile_at(vi + 3), wave, lane);
+        const uint8_t* img = ring + (vi & 3) * Rg::IMG;
         const bool ragged = (tile == ntiles - 1) && (N & 31);
         bool listed = ragged || vi < nown;
         if (!listed) {
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2 * NT; ++ks) s = mfma16(*(const h16x8*)(krow + ks * 32 + hi * 16), qh[ks], s);
-            ord_scores(s, two_cq, xxs[cur], cks[cur], hi);
+            f32x16 s = Rg::head(img, li, hi, qh);
+            ord_scores(s, two_cq, Rg::xxs(img), Rg::cks(img), hi);
             const float reach = fmaf(emul, tsqc[tile], ord_max16(s));
             listed = __builtin_amdgcn_ballot_w64(reach >= Rthr) != 0ull;
         }
         if (listed) {
-            f32x16 s = split_tile_keys_on_rows<NT>(krow, hi, qh, ql);
-            ord_scores(s, two_cq, xxs[cur], cks[cur], hi);
+            f32x16 s = Rg::exact(img, li, hi, qh, ql);
+            ord_scores(s, two_cq, Rg::xxs(img), Rg::cks(img), hi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool pad = ragged && tile * 32 + mfma_row(r, hi) >= N;
@@ -210,16 +262,14 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
             const uint32_t R = kth_bound(16);                   // 16 steps: within 2^-7 of the exact k-th bucket value
             if (R != 0xFFFFFFFFu) Rthr = ord_reach(xq, sortable_f32(R));
         }
-        if (vi + 1 < ntiles) st.store(lds[cur ^ 1], xxs[cur ^ 1], cks[cur ^ 1], tid);
-        __syncthreads();
-        cur ^= 1;
     }
     const uint32_t T = kth_bound(32);
     if (qrow < N && hi == 0) Tbuf[(size_t)cloud * N + qrow] = T;
 
     // the block's list: (tile << 4 | wave mask) in tile order
+    __syncthreads();
     const size_t block = (size_t)cloud * gridDim.x + bxi;
-    unsigned short* bl = blist + block * ntiles;
+    uint32_t* bl = blist + block * ntiles;
     int base = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 256) {
         const int t = t0 + tid;
@@ -232,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
         __syncthreads();
         int pos = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
         for (int w = 0; w < wave; ++w) pos += wsum[w];
-        if (m4) bl[pos] = (unsigned short)((t << 4) | m4);
+        if (m4) bl[pos] = (uint32_t)((t << 4) | m4);
         base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
@@ -245,13 +295,11 @@ __global__ __launch_bounds__(256, 2) void knn_ord_collect_kernel(const float* __
                                                                  const uint32_t* __restrict__ Tbuf, Cand* __restrict__ lists,
                                                                  int* __restrict__ counts, int* __restrict__ overflow,
                                                                  const int* __restrict__ perm,
-                                                                 const unsigned short* __restrict__ blist,
+                                                                 const uint32_t* __restrict__ blist,
                                                                  const int* __restrict__ bcount) {
-    using St = OrdTile<NT>;
-    constexpr int D = St::D, LDX = St::LDX;
-    __shared__ __attribute__((aligned(16))) float lds[2][32 * LDX];
-    __shared__ __attribute__((aligned(16))) float xxs[2][32];
-    __shared__ __attribute__((aligned(16))) float cks[2][32];
+    using Rg = OrdRing<NT>;
+    constexpr int D = Rg::D;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];          // Rg::NBUF tile images
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     int bxi;
@@ -264,34 +312,34 @@ __global__ __launch_bounds__(256, 2) void knn_ord_collect_kernel(const float* __
     const int qrow = bxi * 128 + wave * 32 + li;
     const int qrow_c = qrow < N ? qrow : N - 1;
     const size_t block = (size_t)cloud * gridDim.x + bxi;
-    const unsigned short* bl = blist + block * ntiles;
+    const uint32_t* bl = blist + block * ntiles;
     const int n = bcount[block];
 
     h16x8 qh[2 * NT], ql[2 * NT];
     split_load_query<NT>((const h16*)Xc + (size_t)qrow_c * 2 * D, hi, qh, ql);
-    const float two_cq = 2.0f * invc[qrow_c];
-    const float xq = xxc[qrow_c];
-    const uint32_t T = Tbuf[(size_t)cloud * N + qrow_c];
-    const float Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);      // fewer than k bucket values: take everything
-    const float thr = ord_reach(xq, Tf);
+    float two_cq = 2.0f * invc[qrow_c];
+    float xq = xxc[qrow_c];
+    uint32_t T = Tbuf[(size_t)cloud * N + qrow_c];
+    float Tf = T == 0xFFFFFFFFu ? __builtin_inff() : sortable_f32(T);      // fewer than k bucket values: take everything
+    float thr = ord_reach(xq, Tf);
     Cand* mylist = lists + (((size_t)cloud * N + qrow_c) * 2 + hi) * CAPL;
     int cnt = 0;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) { ORD_SETTLE(qh[ks]); ORD_SETTLE(ql[ks]); }
+    ORD_SETTLE(two_cq); ORD_SETTLE(xq); ORD_SETTLE(T); ORD_SETTLE(Tf); ORD_SETTLE(thr);
 
-    if (n > 0) {
-        St st;
-        st.load(Xc, xxc, invc, N, (int)bl[0] >> 4, tid);
-        st.store(lds[0], xxs[0], cks[0], tid);
-    }
-    __syncthreads();
-    int cur = 0;
+    // (the list entries are 32-bit words at uniform addresses: scalar loads, a different counter than the copies'; the candidates'
+    // original indices come from the tile image, so the loop has no vector load of its own)
+    for (int p = 0; p < 3 && p < n; ++p) Rg::issue(ring, p, Xc, xxc, invc, permc, N, (int)bl[p] >> 4, wave, lane);
     for (int i = 0; i < n; ++i) {
-        const int e = (int)bl[i];
+        const int e = __builtin_amdgcn_readfirstlane((int)bl[i]);
         const int tile = e >> 4;
-        St st;
-        if (i + 1 < n) st.load(Xc, xxc, invc, N, (int)bl[i + 1] >> 4, tid);
+        Rg::wait_publish(n - 1 - i);
+        if (i + 3 < n) Rg::issue(ring, (i + 3) & 3, Xc, xxc, invc, permc, N, __builtin_amdgcn_readfirstlane((int)bl[i + 3]) >> 4, wave, lane);
+        const uint8_t* img = ring + (i & 3) * Rg::IMG;
         if ((e >> wave) & 1) {
-            f32x16 s = split_tile_keys_on_rows<NT>((const uint8_t*)(lds[cur] + li * LDX), hi, qh, ql);
-            ord_scores(s, two_cq, xxs[cur], cks[cur], hi);
+            f32x16 s = Rg::exact(img, li, hi, qh, ql);
+            ord_scores(s, two_cq, Rg::xxs(img), Rg::cks(img), hi);
             const bool ragged = (tile == ntiles - 1) && (N & 31);
             if (ragged || __builtin_amdgcn_ballot_w64(ord_max16(s) >= thr) != 0ull) {
 #pragma unroll
@@ -302,16 +350,13 @@ __global__ __launch_bounds__(256, 2) void knn_ord_collect_kernel(const float* __
                     if (dv <= Tf && !pad) {                          // one branch per value; inside it the append is predicated
                         const uint32_t key = f32_sortable(dv);
                         const bool hit = key <= T;
-                        Cand c; c.key = key; c.idx = permc[tile * 32 + krow];
+                        Cand c; c.key = key; c.idx = Rg::perms(img)[krow];
                         if (hit && cnt < CAPL) mylist[cnt] = c;
                         cnt += hit ? 1 : 0;
                     }
                 }
             }
         }
-        if (i + 1 < n) st.store(lds[cur ^ 1], xxs[cur ^ 1], cks[cur ^ 1], tid);
-        __syncthreads();
-        cur ^= 1;
     }
     if (qrow < N) {
         counts[((size_t)cloud * N + qrow) * 2 + hi] = cnt;

@@ -673,7 +673,7 @@ static int knn_fused_impl(int B, int N, int d, int C, int k, const float* X, int
     dim3 grid((N + 127) / 128, B);
     const int M = pick_M(k);
     // the ordered form: nearest neighbours at the split-fp16 widths, one key chunk, tile maps of <= 512 tiles
-    if (!(perm && !far && (d == 64 || d == 128) && sed_sel_chunks(B, N) == 1 && N <= 32 * ORD_MAXTILES)) perm = nullptr;
+    if (!(perm && !far && (d == 64 || d == 128) && sed_sel_chunks(B, N) == 1 && N <= 32 * ORD_MAXTILES && N % 4 == 0)) perm = nullptr;
     int rc;
     switch (d / 32) {
         case 1: rc = launch_nt<1>(grid, M, X, w, N, k, overflow, far, perm, stream); break;

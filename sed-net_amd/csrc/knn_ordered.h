@@ -55,12 +55,12 @@ __global__ __launch_bounds__(256) void ord_tilemax_kernel(const float* __restric
 // different bank groups --, then the rows' squared norms [32], 2^-e [32] and original indices [32]. A lane's DMA source address is free, so the swizzle
 // costs nothing on the way in. Rows beyond N repeat row N - 1 (the element tests exclude them by index).
 // The copies are inline instructions the compiler does not track (it would wait for ALL of them before every LDS read): a tile is
-// waited for explicitly -- every wave issues PW copies per tile, in order, so "at most 2 PW outstanding" = the tile three back has
+// waited for explicitly -- a wave issues PW (wave 0: PW + 1) copies per tile, in order, so "at most 2 of those outstanding" = the tile three back has
 // landed -- and published by the loop's one barrier, which also says that everyone has finished the tile whose slot is refilled next.
 template <int NT>
 struct OrdRing {
     static constexpr int D = 32 * NT, ROWB = 4 * D, CPR = ROWB / 16, IMG = 32 * ROWB + 512, NBUF = 4;
-    static constexpr int PIECES = 32 * ROWB / 1024, PW = PIECES / 4 + 2;          // per wave and tile: its share of the planes, xx | 2^-e, perm
+    static constexpr int PIECES = 32 * ROWB / 1024, PW = PIECES / 4;              // per wave and tile: its share of the planes (+ 1 for wave 0)
     static_assert(PIECES % 4 == 0, "plane pieces per wave");
     static __device__ __forceinline__ void dma16(const void* g, const uint8_t* l) {
         const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const uint8_t*)l);
@@ -83,19 +83,30 @@ struct OrdRing {
             const int key = tile * 32 + row < N ? tile * 32 + row : N - 1;
             dma16((const uint8_t*)Xc + (size_t)key * ROWB + j * 16, img + piece * 1024);
         }
-        const int r = lane & 31;
-        const int key = tile * 32 + r < N ? tile * 32 + r : N - 1;
-        dma4(lane < 32 ? xxc + key : invc + key, img + 32 * ROWB);
-        dma4(permc + key, img + 32 * ROWB + 256);                  // (both halves of the wave write the same 32 words twice)
+        // wave 0 also brings the rows' constants: 16 B per lane, lanes 0-7 xx, 8-15 2^-e, 16-23 the original indices (every array
+        // is 16-byte aligned per cloud only if N % 4 == 0: the ordered form requires it, knn_fused_impl)
+        if (wave == 0) {
+            const int grp = lane >> 3, r4 = (lane & 7) * 4;
+            int key = tile * 32 + r4;
+            key = key + 3 < N ? key : (N - 4 > 0 ? N - 4 : 0);     // (a ragged tile's tail repeats the cloud's last rows; excluded by index)
+            const void* src = grp == 0 ? (const void*)(xxc + key) : grp == 1 ? (const void*)(invc + key) : (const void*)(permc + key);
+            if (lane < 24) dma16(src, img + 32 * ROWB);
+        }
     }
-    template <int AHEAD>                                            // AHEAD = tiles issued after the one needed now (0 .. 2)
+    template <int AHEAD, int MINE>                                  // AHEAD = tiles issued after the one needed now (0 .. 2)
     static __device__ __forceinline__ void wait_publish() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AHEAD * PW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AHEAD * MINE) : "memory");
     }
-    static __device__ __forceinline__ void wait_publish(int ahead) {
-        if (ahead >= 2) wait_publish<2>();
-        else if (ahead == 1) wait_publish<1>();
-        else wait_publish<0>();
+    static __device__ __forceinline__ void wait_publish(int ahead, int wave) {
+        if (wave == 0) {
+            if (ahead >= 2) wait_publish<2, PW + 1>();
+            else if (ahead == 1) wait_publish<1, PW + 1>();
+            else wait_publish<0, PW + 1>();
+        } else {
+            if (ahead >= 2) wait_publish<2, PW>();
+            else if (ahead == 1) wait_publish<1, PW>();
+            else wait_publish<0, PW>();
+        }
     }
     static __device__ __forceinline__ h16x8 chunk(const uint8_t* img, int row, int j) {
         return *(const h16x8*)(img + row * ROWB + (((j & ~15) | ((j ^ row) & 15)) << 4));
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
     uint32_t (*fl)[ORD_MAXTILES / 32] = (uint32_t (*)[ORD_MAXTILES / 32])(ring + Rg::NBUF * Rg::IMG);
     int* wsum = (int*)(ring + Rg::NBUF * Rg::IMG + 4 * (ORD_MAXTILES / 32) * 4);
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hi = lane >> 5;
     int bxi;
     const int cloud = sed_xcd_cloud_block(&bxi);
     const float* Xc = X + (size_t)cloud * N * D;
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void knn_ord_bound_kernel(const float* __re
     for (int p = 0; p < 3 && p < ntiles; ++p) Rg::issue(ring, p, Xc, xxc, invc, permc, N, tile_at(p), wave, lane);
     for (int vi = 0; vi < ntiles; ++vi) {
         const int tile = tile_at(vi);
-        Rg::wait_publish(ntiles - 1 - vi);
+        Rg::wait_publish(ntiles - 1 - vi, wave);
         if (vi + 3 < ntiles) Rg::issue(ring, (vi + 3) & 3, Xc, xxc, invc, permc, N, tile_at(vi + 3), wave, lane);
         const uint8_t* img = ring + (vi & 3) * Rg::IMG;
         const bool ragged = (tile == ntiles - 1) && (N & 31);
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void knn_ord_collect_kernel(const float* __
     constexpr int D = Rg::D;
     extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];          // Rg::NBUF tile images
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hi = lane >> 5;
     int bxi;
     const int cloud = sed_xcd_cloud_block(&bxi);
     const float* Xc = X + (size_t)cloud * N * D;
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void knn_ord_collect_kernel(const float* __
     for (int i = 0; i < n; ++i) {
         const int e = __builtin_amdgcn_readfirstlane((int)bl[i]);
         const int tile = e >> 4;
-        Rg::wait_publish(n - 1 - i);
+        Rg::wait_publish(n - 1 - i, wave);
         if (i + 3 < n) Rg::issue(ring, (i + 3) & 3, Xc, xxc, invc, permc, N, __builtin_amdgcn_readfirstlane((int)bl[i + 3]) >> 4, wave, lane);
         const uint8_t* img = ring + (i & 3) * Rg::IMG;
         if ((e >> wave) & 1) {

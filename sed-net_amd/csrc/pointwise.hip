@@ -421,6 +421,254 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 6: the WIDE form of pointwise_split_kernel<4, false> -- a wave owns 64 points x 128 channels (two 32-point subtiles), a
+// workgroup 256 points x 128 channels. Why: in the 32-point form every weight operand read from LDS feeds 6 MFMAs (192 matrix
+// cycles for 8 LDS cycles of a ds_read_b128, times 8 waves per CU: the LDS pipe is ~70 % as busy as the matrix pipe would be at
+// its peak, plus 1.16 conflict cycles per instruction from the 16-byte staging stores into 80-byte rows) and every 128 points
+// re-stage the whole weight slice through registers; MFMA-pipe busy 0.38 (profiles/r05_pmc_kernels.md), and halving the MFMAs
+// (the split-fp16 form of round 4) took 18 % off, not 50 %. Here a weight operand feeds 12 MFMAs (the two subtiles), the weight
+// slice is staged once per 256 points, and it travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers,
+// no LDS store instructions) into rows of 64 B whose four 16-byte chunks sit at slot c ^ ((row >> 2) & 3): the 16 lanes a
+// ds_read_b128 serves together read 16 rows at one k offset and land in 16 different bank groups. A lane's DMA source address is
+// free, so the swizzle costs nothing on the way in. The copies are inline instructions: one chunk ahead, waited for by the
+// explicit vmcnt(0) in front of the chunk's barrier (which is also what the chunk's activations, loaded one chunk ahead, need).
+// Same MFMA sequence per accumulator and the same epilogue arithmetic as pointwise_split_kernel => the same bits; GroupNorm
+// partials and column extrema stay per 128-POINT block (a workgroup writes two sets: waves 0, 1 and waves 2, 3), each a sum of
+// four 32-point wave sums in the old order, so gn_finalize's inputs are bit-identical too.
+#ifndef PW_WIDE
+#define PW_WIDE 1                  // 0: A/B builds with the 32-point form of rounds 2-5
+#endif
+#ifndef PW_EXP
+#define PW_EXP 0                   // measurement builds only (results wrong): 1 no epilogue, 2 no operand split, 4 activations loaded
+#endif                             // once, 8 weights staged once, 16 no MFMA  (tools/pointwise_ab.py, profiles/r06_pointwise_wide.md)
+template <int TN>
+__global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __restrict__ X, int ldx, int K,
+                                                                const __bf16* __restrict__ Wp /* [3][Coutp][K] */, int Coutp,
+                                                                const float* __restrict__ bias, const float* __restrict__ cbias,
+                                                                float* __restrict__ Y, int ldy, int Cout,
+                                                                double* __restrict__ part, float* __restrict__ colext, int N,
+                                                                int nblk /* 128-point blocks */, int flags) {
+    constexpr int BN = 32 * TN;
+    constexpr int PLANE = BN * 64;                           // bytes of one weight plane of a stage: BN rows x 32 k bf16
+    constexpr int STG = 3 * PLANE;
+    constexpr int PW = STG / 1024 / 4;                       // 1 KiB DMA pieces per wave and stage
+    static_assert(STG % 4096 == 0, "stage pieces per wave");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t wsm[];
+    uint8_t* Bs = wsm;                                       // [2][STG]
+    double* red = (double*)(Bs + 2 * STG);                   // [2 halves][4 slots][TN][2]
+    float* ext = (float*)(red + 2 * 4 * TN * 2);             // [2 halves][4 slots][BN][2]
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int nz = Coutp / BN, nwt = (nblk + 1) >> 1;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;       // slot -> (point tile, channel block) as in pointwise_split_kernel
+    const int zb = j % nz, pt = (j / nz) * 8 + xcd;
+    if (pt >= nwt) return;
+    const int cloud = blockIdx.y, o0 = zb * BN;
+    const int p0 = pt * 256;
+    const float* Xc = X + (size_t)cloud * N * ldx;
+    const int nchunk = K / 32;
+    const size_t plane = (size_t)Coutp * K;
+
+    const float* xrow[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int r = p0 + wave * 64 + p * 32 + li;
+        if (r >= N) r = N - 1;
+        xrow[p] = Xc + (size_t)r * ldx + 8 * hi;
+    }
+    f32x4 xa[2][4];                                          // [subtile][k-step x first / second float4] of the NEXT chunk
+    auto load_a = [&](int ch) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xa[p][u] = *(const f32x4*)(xrow[p] + ch * 32 + 16 * (u >> 1) + 4 * (u & 1));
+    };
+    // stage copy: 16-byte slot q of the stage = (plane, row, slot in row); it holds chunk c = slot ^ ((row >> 2) & 3) of the row
+    unsigned voff[PW];
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+        const int q = (wave * PW + u) * 64 + lane;
+        const int pl = q / (BN * 4), row = (q >> 2) % BN, c = (q & 3) ^ ((row >> 2) & 3);
+        voff[u] = (unsigned)((pl * plane + (size_t)row * K + 8 * c) * sizeof(__bf16));
+    }
+    const __bf16* wbase = Wp + (size_t)o0 * K;
+    auto stage_dma = [&](int ch, int buf) {
+        const __bf16* src = wbase + ch * 32;
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const unsigned la = __builtin_amdgcn_readfirstlane(
+                (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)(Bs + buf * STG + (wave * PW + u) * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[u]), "s"(src), "s"(la) : "memory");
+        }
+    };
+    const int boff = li * 64, sw = (li >> 2) & 3;            // weight operand of (tile t, k-step s2): row 32 t + li, chunk hi + 2 s2
+    const int bo0 = boff + ((hi ^ sw) << 4), bo1 = boff + (((hi + 2) ^ sw) << 4);
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.f;
+
+    // One chunk. The activations are compiler-tracked loads, the stage copies are not (inline instructions): a compiler-placed
+    // wait for "my loads" in the middle of the chunk would count wrongly and drain the copies just issued. So every value the
+    // chunk needs from memory is consumed (split into its three planes) right behind the explicit wait, BEFORE the next chunk's
+    // loads are issued -- the compiler's own wait lands where nothing is in flight -- and the sched_barrier keeps that order.
+    auto chunk = [&](int ch, int cur) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B(ch), X(ch) landed; everyone is out of the other buffer
+        bf16x8 a1[2][2], a2[2][2], a3[2][2];                   // [k-step][subtile]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (PW_EXP & 2) {
+                    a1[s2][p] = __builtin_bit_cast(bf16x8, f32x4{xa[p][2 * s2][0], xa[p][2 * s2][1], xa[p][2 * s2][2], xa[p][2 * s2][3]});
+                    a2[s2][p] = __builtin_bit_cast(bf16x8, f32x4{xa[p][2 * s2 + 1][0], xa[p][2 * s2 + 1][1], xa[p][2 * s2 + 1][2], xa[p][2 * s2 + 1][3]});
+                    a3[s2][p] = a1[s2][p];
+                } else split3(xa[p][2 * s2], xa[p][2 * s2 + 1], a1[s2][p], a2[s2][p], a3[s2][p]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nchunk) {
+            if (!(PW_EXP & 8)) stage_dma(ch + 1, cur ^ 1);
+            if (!(PW_EXP & 4)) load_a(ch + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint8_t* bb = Bs + cur * STG;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const uint8_t* b = bb + (s2 ? bo1 : bo0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const bf16x8 w1 = *(const bf16x8*)(b + t * 2048);
+                const bf16x8 w2 = *(const bf16x8*)(b + PLANE + t * 2048);
+                const bf16x8 w3 = *(const bf16x8*)(b + 2 * PLANE + t * 2048);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (PW_EXP & 16) {
+#if PW_EXP && defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" ::"v"(w1), "v"(w2), "v"(w3), "v"(a1[s2][p]), "v"(a2[s2][p]), "v"(a3[s2][p]));
+#endif
+                        continue;
+                    }
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2][p], w3, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[s2][p], w1, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][p], w2, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2][p], w2, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][p], w1, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s2][p], w1, acc[p][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    stage_dma(0, 0);
+    load_a(0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        chunk(ch, 0);
+        if (ch + 1 < nchunk) chunk(ch + 1, 1);
+    }
+
+    if (PW_EXP & 1) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+#if PW_EXP && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(acc[p][t]));
+#endif
+            }
+        return;
+    }
+    // ---- epilogue: pointwise_split_kernel's, per 32-point subtile. Wave w, subtile p = slot (2 w + p) & 3 of 128-point block
+    // 2 pt + (w >> 1).
+    const int half = wave >> 1;
+    using TT = std::true_type;
+    using FF = std::false_type;
+    auto subtile = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        const int slot = 2 * (wave & 1) + p;
+        const int pw = p0 + wave * 64 + p * 32;
+        unsigned vmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vmask |= (pw + mfma_row(r, hi) < N ? 1u : 0u) << r;
+        const bool full = pw + 32 <= N;
+        auto tiles = [&](auto relu_c, auto store_c, auto stats_c, auto ext_c, auto full_c) {
+            constexpr bool RELU = decltype(relu_c)::value, STORE = decltype(store_c)::value, STATS = decltype(stats_c)::value,
+                           EXT = decltype(ext_c)::value, FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int o = o0 + 32 * t + li;
+                float add = bias ? bias[o] : 0.f;
+                if (cbias) add += cbias[(size_t)cloud * Coutp + o];
+                float ps = 0.f, pq = 0.f, mx = -3.0e38f, mn = 3.0e38f;
+                const unsigned loff = (unsigned)(4 * hi * ldy + o);
+                const bool och = o < Cout;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[p][t][r] + add;
+                    if (RELU) v = sed_vmax(v, 0.f);
+                    const bool ok = FULL || ((vmask >> r) & 1u);
+                    if (STORE && ok && och) {
+                        float* rowbase = Y + ((size_t)cloud * N + pw + ((r & 3) + 8 * (r >> 2))) * ldy;     // uniform
+                        rowbase[loff] = v;
+                    }
+                    if (ok) {
+                        if (STATS) { ps += v; pq = fmaf(v, v, pq); }
+                        if (EXT) { mx = sed_vmax(mx, v); mn = sed_vmin(mn, v); }
+                    }
+                }
+                if (STATS) {
+                    double d1 = (double)ps, d2 = (double)pq;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+                    if (lane == 0) { red[((half * 4 + slot) * TN + t) * 2] = d1; red[((half * 4 + slot) * TN + t) * 2 + 1] = d2; }
+                }
+                if (EXT) {
+                    mx = fmaxf(mx, xor32(mx));
+                    mn = fminf(mn, xor32(mn));
+                    if (hi == 0) {
+                        ext[((half * 4 + slot) * BN + 32 * t + li) * 2] = mx;
+                        ext[((half * 4 + slot) * BN + 32 * t + li) * 2 + 1] = mn;
+                    }
+                }
+            }
+        };
+        auto with_full = [&](auto relu_c, auto store_c, auto stats_c, auto ext_c) {
+            if (full) tiles(relu_c, store_c, stats_c, ext_c, TT{});
+            else tiles(relu_c, store_c, stats_c, ext_c, FF{});
+        };
+        auto d3 = [&](auto a, auto b, auto c) { if (flags & F_COLEXT) with_full(a, b, c, TT{}); else with_full(a, b, c, FF{}); };
+        auto d2 = [&](auto a, auto b) { if (flags & F_STATS) d3(a, b, TT{}); else d3(a, b, FF{}); };
+        auto d1 = [&](auto a) { if (flags & F_STORE) d2(a, TT{}); else d2(a, FF{}); };
+        if (flags & F_RELU) d1(TT{}); else d1(FF{});
+    };
+    subtile(std::integral_constant<int, 0>{});
+    subtile(std::integral_constant<int, 1>{});
+    if (flags & (F_STATS | F_COLEXT)) __syncthreads();
+    if ((flags & F_STATS) && tid < 2 * TN * 2) {
+        const int h = tid / (TN * 2), t = (tid >> 1) % TN, which = tid & 1;
+        if (2 * pt + h < nblk) {
+            double s = 0.0;
+            for (int w = 0; w < 4; ++w) s += red[((h * 4 + w) * TN + t) * 2 + which];
+            const int ntile = nz * TN;
+            part[(((size_t)cloud * nblk + 2 * pt + h) * ntile + zb * TN + t) * 2 + which] = s;
+        }
+    }
+    if ((flags & F_COLEXT) && tid < 2 * BN) {
+        const int h = tid / BN, c = tid % BN;
+        if (2 * pt + h < nblk) {
+            float mx = -3.0e38f, mn = 3.0e38f;
+            for (int w = 0; w < 4; ++w) { mx = fmaxf(mx, ext[((h * 4 + w) * BN + c) * 2]); mn = fminf(mn, ext[((h * 4 + w) * BN + c) * 2 + 1]); }
+            float* dst = colext + (((size_t)cloud * nblk + 2 * pt + h) * Coutp + o0 + c) * 2;
+            dst[0] = mx;
+            dst[1] = mn;
+        }
+    }
+}
+
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int nblk, int ntile, int G, double count,
                                    float eps, float* __restrict__ stats) {
     // one wave per (cloud, group): lane l adds entries l, l + 64, ... of the group's nblk x tpg partial pairs, then a fixed
@@ -718,8 +966,19 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
             hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
             if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)pointwise_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            if (e != hipSuccess) return (int)e;
             sed_mark_device(attr_set);
         } else if (attr_set_err) return attr_set_err;
+        // both forms give the same bits: the wide one when the 32-point form's grid fills the chip's 512 workgroup slots at least
+        // twice (a call with one or two clouds keeps the finer tiles: 80 workgroups of 256 points would leave CUs empty)
+        if (PW_WIDE && (long)nblk * (Coutp / 128) * B >= 1024) {
+            const int nwt8 = ((nblk + 1) / 2 + 7) / 8 * 8;
+            const size_t sm = 2 * 3 * 128 * 64 + 2 * 4 * 4 * 2 * sizeof(double) + 2 * 4 * 128 * 2 * sizeof(float);
+            pointwise_wide_kernel<4><<<dim3(nwt8 * (Coutp / 128), B), 256, sm, stream>>>(
+                X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
+                flags);
+        } else
         pointwise_split_kernel<4, false><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags, nullptr);

@@ -199,6 +199,42 @@ def test_split_bf16_gemm_equals_fp32_gemm(T, K, Cout, flags_relu):
         np.testing.assert_allclose(ss.cpu().numpy(), sf.cpu().numpy(), rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,K,Cout,flags", [(3000, 256, 256, 6), (2999, 512, 128, 6), (1537, 256, 1024, 12), (1290, 32, 256, 3),
+                                            (2100, 256, 256, 14)])
+def test_wide_and_narrow_tiles_of_the_split_gemm_agree_bit_for_bit(T, N, K, Cout, flags):
+    """Round 6: sed_pointwise_fwd_split_f32 runs 256-point workgroups (pointwise_wide_kernel: a wave owns 64 points, weight
+    operands feed two subtiles, weights staged by LDS-DMA) when the call is large and the 128-point form of rounds 2-5 when it
+    is small (a call with one cloud). Same MFMA sequence per accumulator, same epilogue arithmetic, GroupNorm partials per
+    128-point block in the old order: the outputs, the statistics and the column extrema of a cloud must not depend on which
+    form ran -- a batch of clouds (wide) against the same clouds one per call (narrow), ragged last tiles included."""
+    from sednet_hip import ops
+    B = 48
+    assert ((N + 127) // 128) * (Cout // 128) * B >= 1024 > ((N + 127) // 128) * (Cout // 128)      # batch: wide; one cloud: narrow
+    g = T.Generator().manual_seed(N + K + Cout)
+    X = T.randn(B, N, K, generator=g).cuda()
+    Wt = (T.randn(K, Cout, generator=g) / K ** 0.5).cuda()
+    bias = T.randn(Cout, generator=g).cuda()
+    cb = T.randn(B, Cout, generator=g).cuda()
+    G = 4 if flags & ops.F_STATS else 0
+    nblk = (N + 127) // 128
+    Yw, sw, cw = ops.pointwise(X, Wt, Cout, bias=bias, cbias=cb, flags=flags, G=G, split=True)
+    for b in (0, 17, B - 1):
+        Yn, sn, cn = ops.pointwise(X[b:b + 1], Wt, Cout, bias=bias, cbias=cb[b:b + 1], flags=flags, G=G, split=True)
+        if flags & ops.F_STORE:
+            assert T.equal(Yw[b], Yn[0])
+        if flags & ops.F_STATS:
+            assert T.equal(sw[b], sn[0])
+        if flags & ops.F_COLEXT:
+            per = nblk * Cout * 2
+            assert T.equal(cw.view(T.float32)[b * per:(b + 1) * per], cn.view(T.float32)[:per])
+    if flags & ops.F_STORE:      # and the values are right
+        ref = X[:2].double() @ Wt.double() + bias.double() + cb[:2, None].double()
+        if flags & ops.F_RELU:
+            ref = ref.clamp_min(0)
+        scale = (X[:2].double().abs() @ Wt.double().abs() + bias.double().abs() + cb[:2, None].double().abs())
+        assert float(((Yw[:2].double() - ref).abs() / scale).max()) < 4e-7
+
+
 @pytest.mark.parametrize("K,Cout,flags_relu", [(256, 1024, False), (512, 256, True), (256, 128, False)])
 def test_split_fp16_gemm_with_row_bounds_equals_fp32_gemm(T, K, Cout, flags_relu, monkeypatch):
     """pointwise_split_kernel<4, true>: two fp16 planes per operand, rows scaled by the bound the producer left (here: the exact

@@ -158,8 +158,11 @@ __global__ __launch_bounds__(RITZ_THREADS) void ritz_kernel(const double* __rest
     __shared__ int pq[MMAX];
     __shared__ int top[MMAX];
     __shared__ double red[2 * RITZ_THREADS / 64];
+    __shared__ double dsc[MMAX];                              // (eigen route) 1 / |s_j|: the block's columns scaled to unit length
+    __shared__ int drop[MMAX];                                // (eigen route) whitened directions that were cut off
     constexpr int NTH = RITZ_THREADS;
     const int cloud = blockIdx.x, lane = threadIdx.x;
+    if (lane < MMAX) drop[lane] = 0;
     const double* Gc = G + (size_t)cloud * m * m;
     const double* Hc = H + (size_t)cloud * m * m;
     for (int e = lane; e < m * m; e += NTH) {
@@ -169,8 +172,17 @@ __global__ __launch_bounds__(RITZ_THREADS) void ritz_kernel(const double* __rest
     }
     __syncthreads();
     // Whitening Wh with Wh^T G Wh = I. Usual case: Cholesky G = L L^T, Wh = L^-T (a 36-step column sweep + a forward substitution
-    // per lane: a fraction of a Jacobi decomposition). If [X, R, P] is numerically dependent (a pivot below 1e-5 of the largest,
+    // per lane: a fraction of a Jacobi decomposition). If [X, R, P] is numerically dependent (a pivot below 1e-3 of the largest,
     // or not finite) the eigen-decomposition of G with a cut-off is used instead, like round 2's host solver.
+    // Round 6 (the root cause of the intermittent abort of rounds 4-5): the block update S C runs in
+    // fp32, so a whitening that scales a direction by 1 / sqrt(w) multiplies the update's rounding by the same factor. Rounds 3-5
+    // accepted Cholesky pivots down to 1e-5 of the largest and, in the eigen route, directions down to 1e-10 of the largest
+    // eigenvalue of the UNSCALED Gram matrix: on a cloud whose leading pairs converge within three iterations (P collapses onto
+    // span [X, R]) about 4 % of the random starts amplified noise by 1e5, P grew to 1e4, the cut-off -- relative to P's 1e9 --
+    // then removed the unit-length X directions themselves, zero Ritz values entered the top k, X got zero columns and the
+    // eigenvector entropy divided by a zero interval: NaN spectral columns, non-unit rows into the clustering stage. Now: Cholesky
+    // only for pivot ratios >= 1e-3; otherwise the columns are scaled to unit length first, directions below 1e-6 of the largest
+    // eigenvalue of the SCALED Gram matrix are cut (amplification <= 1e3), and a cut direction can never be selected.
     for (int e = lane; e < m * m; e += NTH) Tm[e / m][e % m] = A[e / m][e % m];        // L is built in Tm (lower triangle)
     __syncthreads();
     bool ok = true;
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(RITZ_THREADS) void ritz_kernel(const double* __rest
         if (lane >= j && lane < m) Tm[lane][j] = lane == j ? dj : Tm[lane][j] / dj;
         __syncthreads();
     }
-    ok = ok && dmin >= 1e-5 * dmax;
+    ok = ok && dmin >= 1e-3 * dmax;
     if (ok) {
         // lane c: column c of L^-1 by forward substitution (y_i = (delta_ic - sum_{l<i} L_il y_l) / L_ii), stored as Wh[c][i] = (L^-T)
         if (lane < m) {
@@ -207,13 +219,28 @@ __global__ __launch_bounds__(RITZ_THREADS) void ritz_kernel(const double* __rest
         }
         __syncthreads();
     } else {
+        if (lane < m) {
+            const double g = A[lane][lane];
+            dsc[lane] = (g > 0.0 && g < 1e300) ? 1.0 / sqrt(g) : 0.0;       // a zero or non-finite column leaves the block
+        }
+        __syncthreads();
+        for (int e = lane; e < m * m; e += NTH) {
+            const int i = e / m, j = e % m;
+            const double v = A[i][j] * dsc[i] * dsc[j];
+            Tm[i][j] = (v == v && fabs(v) < 1e300) ? v : 0.0;
+        }
+        __syncthreads();
+        for (int e = lane; e < m * m; e += NTH) A[e / m][e % m] = Tm[e / m][e % m];
+        __syncthreads();
         jacobi_eigh<M>(A, V, cs, pq, lane, red);
         double wmax = 0.0;
         for (int j = 0; j < m; ++j) wmax = fmax(wmax, A[j][j]);
         for (int e = lane; e < m * m; e += NTH) {
             const int i = e / m, j = e % m;
             const double w = A[j][j];
-            Wh[i][j] = (w > 1e-10 * wmax && w > 0.0) ? V[i][j] / sqrt(w) : 0.0;
+            const bool keep = w > 1e-6 * wmax && w > 0.0;
+            Wh[i][j] = keep ? dsc[i] * V[i][j] / sqrt(w) : 0.0;
+            if (i == 0) drop[j] = keep ? 0 : 1;
         }
         __syncthreads();
     }
@@ -243,11 +270,14 @@ __global__ __launch_bounds__(RITZ_THREADS) void ritz_kernel(const double* __rest
     __syncthreads();
     jacobi_eigh<M>(A, V, cs, pq, lane, red);
     if (lane == 0) {                                          // the k largest Ritz values, descending, ties -> lowest index
+        // (a cut direction is decoupled -- its row and column of the whitened problem are zero, Jacobi never rotates it -- and must
+        //  not be taken for a Ritz pair with value 0)
+        auto val = [&](int t) { return drop[t] ? -1e300 : A[t][t]; };
         for (int j = 0; j < m; ++j) top[j] = j;
         for (int a = 0; a < k; ++a) {
             int best = a;
             for (int b2 = a + 1; b2 < m; ++b2)
-                if (A[top[b2]][top[b2]] > A[top[best]][top[best]]) best = b2;
+                if (val(top[b2]) > val(top[best])) best = b2;
             const int t = top[a]; top[a] = top[best]; top[best] = t;
         }
     }

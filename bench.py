@@ -269,7 +269,9 @@ def roofline_block(timers, N, iterations, digits, counters=None):
         blk["executed_share_of_dense_work"] = share
         blk["note"] += (f"; block-sparse schedule: 32 x 32 blocks whose kernel weights are all <= e^{ops.MS_SPARSE_SKIP:g} = 2^-39 "
                         "(what fp16(2^14 p) rounds to zero in the dense kernel too) are skipped")
-    pmc = os.path.join(ROOT, "profiles", "r05_pmc_ms_iterate.json")
+    pmc = os.path.join(ROOT, "profiles", "r06_pmc_ms_iterate.json")          # the newest counter record of this kernel
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r05_pmc_ms_iterate.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
         if rec.get("kernel", "").split("<")[0] == blk["kernel"].split("<")[0] and rec.get("clouds") == int(avg_clouds):

@@ -218,18 +218,43 @@ __device__ __forceinline__ void split2(const f32x4& lo, const f32x4& hi4, float 
     for (int e = 0; e < 8; ++e) { h16 a, b; split_pair(e < 4 ? lo[e & 3] : hi4[e & 3], scale, a, b); h[e] = a; l[e] = b; }
 }
 
+// GNIN (round 6): X is a layer's PRE-normalisation output and the kernel applies that layer's GroupNorm + activation to every value as
+// it arrives -- x = act(fmaf(X, a_k, b_k)), a_k = rstd_g gamma_k, b_k = fmaf(-a_k, mean_g, beta_k): gn_apply_kernel's arithmetic, the
+// same bits -- so the normalised tensor is never written or read (a_k, b_k of the cloud sit in LDS: 4 KiB for K <= 512).
+struct GnIn { const float *stats, *gamma, *beta; int G, act; };
+__device__ __forceinline__ void gn_in_table(const GnIn& gi, int cloud, int K, float* coef /* [2][K] */, int tid) {
+    const int cpg = K / gi.G;
+    for (int k = tid; k < K; k += 256) {
+        const int g = k / cpg;
+        const float mean = gi.stats[((size_t)cloud * gi.G + g) * 2], rstd = gi.stats[((size_t)cloud * gi.G + g) * 2 + 1];
+        const float a = rstd * gi.gamma[k];
+        coef[k] = a;
+        coef[K + k] = fmaf(-a, mean, gi.beta[k]);
+    }
+}
+__device__ __forceinline__ f32x4 gn_in_apply(const f32x4& x, const f32x4& a, const f32x4& b, int act) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = fmaf(x[e], a[e], b[e]);
+        if (act == 1) v = fmaxf(v, 0.f);
+        o[e] = v;
+    }
+    return o;
+}
+
 // H16: the two-plane split-fp16 form (split16.h) for inputs whose per-row magnitude bound the producer has already written
 // (`rowmax`, sed_gn_apply_f32): 3 fp16 MFMAs per 16 k instead of 6 bf16 ones, 2 weight planes instead of 3, a 5-instruction
 // split per activation instead of 9. The rows are scaled by 2^e (row bound in [2^13, 2^14)), the weights per output channel
 // (winv = 2^-e behind the planes); the epilogue unscales by the exact product of the two powers of two.
-template <int TN, bool H16>
+template <int TN, bool H16, bool GNIN = false>
 __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __restrict__ X, int ldx, int K,
                                                                  const __bf16* __restrict__ Wp /* [3 | 2][Coutp][K] */,
                                                                  int Coutp, const float* __restrict__ bias,
                                                                  const float* __restrict__ cbias, float* __restrict__ Y,
                                                                  int ldy, int Cout, double* __restrict__ part,
                                                                  float* __restrict__ colext, int N, int nblk, int flags,
-                                                                 const unsigned* __restrict__ rowmax) {
+                                                                 const unsigned* __restrict__ rowmax, GnIn gi = GnIn{}) {
     constexpr int BN = 32 * TN;
     constexpr int LDH = 40;                                  // 16-bit values per LDS row (32 k + 8 pad = 80 B)
     constexpr int NP = H16 ? 2 : 3;                          // weight planes
@@ -239,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
     double* red = (double*)(Bs + 2 * NP * BN * LDH);         // [4][TN][2]
     float* ext = (float*)(red + 4 * TN * 2);                 // [4][BN][2]
     float* ainv_s = ext + 4 * BN * 2;                        // [4][32] (H16): 2^-e of the waves' rows
+    float* coef = ainv_s + 4 * 32;                           // (GNIN) [2][K]: a_k | b_k of this cloud (pointwise_wide_kernel)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     // slot -> (point tile, channel block): slots L, L + 8, L + 16, ... run on XCD L % 8; consecutive slots of one XCD walk
@@ -253,6 +279,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
     const int nchunk = K / 32;
     const size_t plane = (size_t)Coutp * K;
 
+    if (GNIN) gn_in_table(gi, cloud, K, coef, tid);          // visible after the barrier in front of the chunk loop
     int prow = p0 + wave * 32 + li;
     if (prow >= N) prow = N - 1;
     const float* xrow = Xc + (size_t)prow * ldx + 8 * hi;
@@ -293,6 +320,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
     auto step = [&](int ch, f32x4* xa, int cur) {
         bf16x8 a1[2], a2[2], a3[2];
         h16x8 ah[2], al[2];
+        if (GNIN) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = ch * 32 + 16 * (u >> 1) + 8 * hi + 4 * (u & 1);
+                xa[u] = gn_in_apply(xa[u], *(const f32x4*)(coef + k), *(const f32x4*)(coef + K + k), gi.act);
+            }
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (H16) split2(xa[2 * s2], xa[2 * s2 + 1], ascale, ah[s2], al[s2]);
@@ -442,13 +476,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_split_kernel(const float* __
 #ifndef PW_EXP
 #define PW_EXP 0                   // measurement builds only (results wrong): 1 no epilogue, 2 no operand split, 4 activations loaded
 #endif                             // once, 8 weights staged once, 16 no MFMA  (tools/pointwise_ab.py, profiles/r06_pointwise_wide.md)
-template <int TN>
+template <int TN, bool GNIN>
 __global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __restrict__ X, int ldx, int K,
                                                                 const __bf16* __restrict__ Wp /* [3][Coutp][K] */, int Coutp,
                                                                 const float* __restrict__ bias, const float* __restrict__ cbias,
                                                                 float* __restrict__ Y, int ldy, int Cout,
                                                                 double* __restrict__ part, float* __restrict__ colext, int N,
-                                                                int nblk /* 128-point blocks */, int flags) {
+                                                                int nblk /* 128-point blocks */, int flags, GnIn gi) {
     constexpr int BN = 32 * TN;
     constexpr int PLANE = BN * 64;                           // bytes of one weight plane of a stage: BN rows x 32 k bf16
     constexpr int STG = 3 * PLANE;
@@ -458,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __r
     uint8_t* Bs = wsm;                                       // [2][STG]
     double* red = (double*)(Bs + 2 * STG);                   // [2 halves][4 slots][TN][2]
     float* ext = (float*)(red + 2 * 4 * TN * 2);             // [2 halves][4 slots][BN][2]
+    float* coef = ext + 2 * 4 * BN * 2;                      // (GNIN) [2][K]: a_k | b_k of this cloud
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int nz = Coutp / BN, nwt = (nblk + 1) >> 1;
@@ -469,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __r
     const float* Xc = X + (size_t)cloud * N * ldx;
     const int nchunk = K / 32;
     const size_t plane = (size_t)Coutp * K;
+    if (GNIN) gn_in_table(gi, cloud, K, coef, tid);          // visible after the first chunk's barrier
 
     const float* xrow[2];
 #pragma unroll
@@ -520,6 +556,15 @@ __global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __r
     auto chunk = [&](int ch, int cur) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B(ch), X(ch) landed; everyone is out of the other buffer
         bf16x8 a1[2][2], a2[2][2], a3[2][2];                   // [k-step][subtile]
+        if (GNIN) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = ch * 32 + 16 * (u >> 1) + 8 * hi + 4 * (u & 1);
+                const f32x4 ca = *(const f32x4*)(coef + k), cb = *(const f32x4*)(coef + K + k);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xa[p][u] = gn_in_apply(xa[p][u], ca, cb, gi.act);
+            }
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -946,9 +991,30 @@ extern "C" int sed_pointwise_split_weights_f32(int Cout, int Coutp, int K, const
 
 // sed_pointwise_fwd_f32 with the products on the bf16 matrix pipe (three-way split, fp32-equivalent; see
 // pointwise_split_kernel). wsplit = the image written by sed_pointwise_split_weights_f32 for the same (Coutp, K).
+static int pointwise_split_launch(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
+                                  const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext, int flags,
+                                  const GnIn* gn, hipStream_t stream);
 extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
                                            const void* wsplit, const float* bias, const float* cbias, float* Y, int ldy,
                                            void* partials, void* colext, int flags, hipStream_t stream) {
+    return pointwise_split_launch(B, N, K, Coutp, Cout, X, ldx, wsplit, bias, cbias, Y, ldy, partials, colext, flags, nullptr, stream);
+}
+// The same GEMM on a layer's PRE-normalisation output: every activation goes through that layer's GroupNorm + activation as it
+// is loaded, x = act(X a_k + b_k) with a_k = rstd_g gamma_k, b_k = beta_k - mean_g a_k -- sed_gn_apply_f32's arithmetic (scale 1, no
+// addend), the same bits -- so the normalised tensor is never written or read. in_stats [B][in_G][2] (sed_gn_finalize_f32), in_gamma /
+// in_beta [K], in_act 0 none / 1 ReLU. K <= 512, K % in_G == 0, Coutp % 128 == 0.
+extern "C" int sed_pointwise_fwd_split_gn_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
+                                              const void* wsplit, const float* in_stats, const float* in_gamma,
+                                              const float* in_beta, int in_G, int in_act, const float* bias, const float* cbias,
+                                              float* Y, int ldy, void* partials, void* colext, int flags, hipStream_t stream) {
+    if (!in_stats || !in_gamma || !in_beta || in_G <= 0 || (in_act != 0 && in_act != 1)) return SED_EINVAL;
+    if (K > 512 || K % in_G != 0 || Coutp % 128 != 0) return SED_EUNSUPPORTED;
+    const GnIn gn{in_stats, in_gamma, in_beta, in_G, in_act};
+    return pointwise_split_launch(B, N, K, Coutp, Cout, X, ldx, wsplit, bias, cbias, Y, ldy, partials, colext, flags, &gn, stream);
+}
+static int pointwise_split_launch(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
+                                  const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext, int flags,
+                                  const GnIn* gn, hipStream_t stream) {
     if (B <= 0 || N <= 0 || !X || !wsplit) return SED_EINVAL;
     if (K % 32 != 0 || Coutp % 64 != 0 || ldx % 4 != 0 || ldx < K || Cout > Coutp) return SED_EUNSUPPORTED;
     if ((flags & F_STORE) && (!Y || ldy < Cout)) return SED_EINVAL;
@@ -966,7 +1032,12 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
             hipError_t e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
             if (e != hipSuccess) return (int)e;
-            e = hipFuncSetAttribute((const void*)pointwise_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            e = hipFuncSetAttribute((const void*)pointwise_wide_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)pointwise_wide_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            if (e != hipSuccess) return (int)e;
+            e = hipFuncSetAttribute((const void*)pointwise_split_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    72 * 1024);
             if (e != hipSuccess) return (int)e;
             sed_mark_device(attr_set);
         } else if (attr_set_err) return attr_set_err;
@@ -974,15 +1045,27 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
         // twice (a call with one or two clouds keeps the finer tiles: 80 workgroups of 256 points would leave CUs empty)
         if (PW_WIDE && (long)nblk * (Coutp / 128) * B >= 1024) {
             const int nwt8 = ((nblk + 1) / 2 + 7) / 8 * 8;
-            const size_t sm = 2 * 3 * 128 * 64 + 2 * 4 * 4 * 2 * sizeof(double) + 2 * 4 * 128 * 2 * sizeof(float);
-            pointwise_wide_kernel<4><<<dim3(nwt8 * (Coutp / 128), B), 256, sm, stream>>>(
+            const size_t sm = 2 * 3 * 128 * 64 + 2 * 4 * 4 * 2 * sizeof(double) + 2 * 4 * 128 * 2 * sizeof(float) +
+                              (gn ? 2 * 512 * sizeof(float) : 0);
+            if (gn)
+                pointwise_wide_kernel<4, true><<<dim3(nwt8 * (Coutp / 128), B), 256, sm, stream>>>(
+                    X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
+                    flags, *gn);
+            else
+                pointwise_wide_kernel<4, false><<<dim3(nwt8 * (Coutp / 128), B), 256, sm, stream>>>(
+                    X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
+                    flags, GnIn{});
+        } else if (gn)
+            pointwise_split_kernel<4, false, true><<<dim3(nblk8 * (Coutp / 128), B), 256,
+                                                     smem(128, 4) + 4 * 32 * sizeof(float) + 2 * 512 * sizeof(float), stream>>>(
                 X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
-                flags);
-        } else
+                flags, nullptr, *gn);
+        else
         pointwise_split_kernel<4, false><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags, nullptr);
     } else {
+        if (gn) return SED_EUNSUPPORTED;
         pointwise_split_kernel<2, false><<<dim3(nblk8 * (Coutp / 64), B), 256, smem(64, 2), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags, nullptr);

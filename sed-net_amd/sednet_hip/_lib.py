@@ -96,6 +96,8 @@ SIGNATURES = {
     "sed_pointwise_split_weights_bytes": (c_size_t, [c_int, c_int]),
     "sed_pointwise_split_weights_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P]),
     "sed_pointwise_fwd_split_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P]),
+    "sed_pointwise_fwd_split_gn_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, c_int, P, P, P, c_int, P, P,
+                                               c_int, P]),
     "sed_segment_metrics_workspace_bytes": (c_size_t, [c_int, c_int]),
     "sed_segment_metrics_f32": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "sed_pointwise_split16_weights_bytes": (c_size_t, [c_int, c_int]),

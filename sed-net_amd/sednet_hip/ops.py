@@ -70,6 +70,7 @@ def _fused_ws(B, N, device):
 
 
 KNN_ORDER = True        # feature-space kNN sweeps on a Morton order of the input cloud (round 6; neighbours do not depend on it)
+GN_ON_LOAD = __import__("os").environ.get("SED_GN_ON_LOAD", "1") != "0"    # round 6: bn1 / bn2 of the head are applied by the consuming GEMM while it loads (same bits)
 
 
 def spatial_order(x6):
@@ -804,10 +805,20 @@ def _split16_weights(Wt):
     return ws
 
 
-def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None, rowmax=None):
+def gn_in_ok(K, Coutp, split=None):
+    """can pointwise(..., gn_in=...) take this layer? (the 3-way bf16 split kernels, K <= 512, Coutp % 128 == 0)"""
+    split = POINTWISE_SPLIT if split is None else split
+    return bool(GN_ON_LOAD and split and not POINTWISE_SPLIT16 and K <= 512 and Coutp % 128 == 0)
+
+
+def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None, rowmax=None,
+              gn_in=None):
     """Y = X Wt + bias + cbias. X [B,N,ldx] view (K = Wt.shape[0] columns used), Wt [K,Coutp]. bf16: products in bf16
     (training). split (default POINTWISE_SPLIT): products by 3-way bf16 split emulation on the bf16 matrix pipe; with rowmax (the
     bounds gn_apply left for X's rows) and Coutp % 128 == 0: by the two-plane split-fp16 form.
+    gn_in = (stats [B,Gin,2], gamma [K], beta [K], Gin, act): X is the PRE-normalisation output of the layer in front and the kernel
+    applies that layer's GroupNorm + activation (ACT_NONE / ACT_RELU) while loading -- gn_apply's arithmetic, the same bits, without
+    the normalised tensor ever being written (round 6; needs gn_in_ok(K, Coutp)).
     Returns (Y view or None, stats [B,G,2] or None, colext bytes or None)."""
     B, N = X.shape[0], X.shape[1]
     K, Coutp = Wt.shape
@@ -818,7 +829,14 @@ def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, 
     colext = _bytes(lib.sed_pointwise_colext_bytes(B, N, Coutp), dev) if flags & F_COLEXT else None
     split = POINTWISE_SPLIT if split is None else split
     extra = ()
-    if bf16:
+    if gn_in is not None:
+        if bf16 or not gn_in_ok(K, Coutp, split):
+            raise ValueError("pointwise(gn_in=...): only the 3-way bf16 split kernels take a pre-normalisation input (gn_in_ok)")
+        st, gamma, beta, Gin, act = gn_in
+        if act not in (ACT_NONE, ACT_RELU) or tuple(st.shape) != (B, Gin, 2) or gamma.numel() < K or beta.numel() < K:
+            raise ValueError("pointwise(gn_in=...): stats [B,Gin,2], gamma / beta [K], act none or ReLU")
+        fwd, wptr, extra = lib.sed_pointwise_fwd_split_gn_f32, ptr(_split_weights(Wt)), (ptr(st), ptr(gamma), ptr(beta), int(Gin), int(act))
+    elif bf16:
         fwd, wptr = lib.sed_pointwise_fwd_bf16, ptr(Wt)
     elif split and rowmax is not None and POINTWISE_SPLIT16 and Coutp % 128 == 0:
         fwd, wptr, extra = lib.sed_pointwise_fwd_split16_f32, ptr(_split16_weights(Wt)), (ptr(rowmax),)

@@ -262,14 +262,19 @@ class SEDNet(nn.Module):
         return self._cache
 
     def _conv_gn_relu(self, X, conv_key, bn_key, G, C, eps, act=ops.ACT_RELU, scale=1.0, addend=None, cbias=None,
-                      Wt=None, bias=None, x_bound=None, y_bound=None):
-        """x_bound: the row bounds of X (-> the split-fp16 product); y_bound: row bounds to raise with the result's rows"""
+                      Wt=None, bias=None, x_bound=None, y_bound=None, gn_in=None, lazy=False):
+        """x_bound: the row bounds of X (-> the split-fp16 product); y_bound: row bounds to raise with the result's rows.
+        gn_in: X is the pre-normalisation output of the layer in front, normalised by the GEMM while it loads (ops.pointwise).
+        lazy: do not apply this layer's GroupNorm + activation -- return (Y raw, gn_in tuple for the consumers) instead of the
+        normalised tensor (round 6: bn1 -> conv2 and bn2 -> prim1 / seg1 never materialise their outputs; same bits)."""
         c = self._prepared()
         if Wt is None:
             Wt, bias = c[conv_key]
         Y, stats, _ = ops.pointwise(X, Wt, C, bias=bias, cbias=cbias, flags=ops.F_STORE | ops.F_STATS, G=G, eps=eps,
-                                    rowmax=x_bound)
+                                    rowmax=x_bound, gn_in=gn_in)
         gamma, beta = c[bn_key]
+        if lazy:
+            return Y, (stats, gamma, beta, G, act)
         return ops.gn_apply(Y, C, G, stats, gamma, beta, act, Y, scale=scale, addend=addend, rowmax=y_bound)
 
     def forward_point_major(self, points, idx1=None, order=None):
@@ -290,11 +295,18 @@ class SEDNet(nn.Module):
             x4, feats = self.encoder.forward_point_major(points, idx1, feats_bound=bnd[0], order=order)
             # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
             cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
-            a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"],
-                                    x_bound=bnd[0], y_bound=bnd[1])
-            x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps, x_bound=bnd[1], y_bound=bnd[2])   # :304
+            # bn1 and bn2 have GEMM consumers only (conv2; mlp_prim_prob1 + mlp_seg_prob1): those apply them while loading
+            fold = ops.gn_in_ok(512, 256) and ops.gn_in_ok(256, 256)
+            if fold:
+                y1, g1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"], lazy=True)
+                x_all, g_all = self._conv_gn_relu(y1, "conv2", "bn2", 4, 256, self.bn2.eps, gn_in=g1, lazy=True)       # :304
+            else:
+                a1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"],
+                                        x_bound=bnd[0], y_bound=bnd[1])
+                x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps, x_bound=bnd[1], y_bound=bnd[2])   # :304
+                g_all = None
             x_type = self._conv_gn_relu(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps,
-                                        x_bound=bnd[2], y_bound=bnd[3])                               # :311
+                                        x_bound=bnd[2], y_bound=bnd[3], gn_in=g_all)                  # :311
             P = self.num_primitives
             te = torch.zeros((B, N, 32), dtype=torch.float32, device=dev)       # cat(type_logit, edges), K padded
             Wt, b = c["prim2"]
@@ -304,7 +316,7 @@ class SEDNet(nn.Module):
                                     x_bound=bnd[3])
             Wt, b = c["edge2"]
             ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2])                                  # :316-317
-            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2])   # :320
+            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2], gn_in=g_all)   # :320
             x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
                                    scale=self.w_pos_enc, addend=xs, x_bound=bnd[3])                    # :322
             Wt, b = c["penc"]

@@ -51,7 +51,7 @@ def test_ctypes_table_matches_header(lib):
 def test_identity_and_argument_validation(lib):
     lib.sed_build_arch.restype = ctypes.c_char_p
     assert lib.sed_build_arch() == b"gfx950"
-    assert lib.sed_abi_version() == 7                     # bumped on any signature change (round 6: ordered kNN sweeps)
+    assert lib.sed_abi_version() == 8                     # bumped on any signature change (round 6: ordered kNN sweeps, GroupNorm-on-load GEMM)
     assert "ABI version %d" % lib.sed_abi_version() in open(os.path.join(ROOT, "DESIGN.md")).read()
     # NULL pointers / bad sizes are rejected before anything is launched
     assert lib.sed_ms_iterate_f32(1, 10, 128, 5, None, None, None, None) == -1

@@ -235,6 +235,48 @@ def test_wide_and_narrow_tiles_of_the_split_gemm_agree_bit_for_bit(T, N, K, Cout
         assert float(((Yw[:2].double() - ref).abs() / scale).max()) < 4e-7
 
 
+@pytest.mark.parametrize("B,N,K,Cout,Gin,act", [(48, 3000, 512, 256, 8, 1), (1, 3000, 512, 256, 8, 1), (48, 1290, 256, 256, 4, 1),
+                                                  (2, 777, 256, 128, 4, 0), (40, 2100, 32, 256, 2, 1)])
+def test_groupnorm_on_load_gives_the_bits_of_gn_apply_then_gemm(T, B, N, K, Cout, Gin, act):
+    """sed_pointwise_fwd_split_gn_f32 (round 6, ABI 8): the GEMM applies the GroupNorm + activation of the layer in front to every
+    activation while loading it. Same arithmetic as sed_gn_apply_f32 (a = rstd gamma, b = fmaf(-a, mean, beta), x = act(fmaf(y, a, b)))
+    => outputs and statistics BIT-IDENTICAL to normalising first and multiplying then, in the wide form (many clouds) and in the
+    128-point form (one or two clouds); negative gammas, an all-zero channel and a ragged last tile included."""
+    from sednet_hip import ops
+    g = T.Generator().manual_seed(B * 7 + N + K)
+    Yin = (T.randn(B, N, K, generator=g) * 3.0 + 0.5).cuda()
+    Yin[:, :, 5] = 0.0
+    stats = T.stack([T.randn(B, Gin, generator=g) * 0.3, T.rand(B, Gin, generator=g) + 0.2], 2).cuda().contiguous()
+    gamma = T.randn(K, generator=g).cuda()
+    beta = T.randn(K, generator=g).cuda()
+    Wt = (T.randn(K, Cout, generator=g) / K ** 0.5).cuda()
+    bias = T.randn(Cout, generator=g).cuda()
+    assert ops.gn_in_ok(K, Cout)
+    Xn = ops.gn_apply(Yin, K, Gin, stats, gamma, beta, ops.ACT_RELU if act else ops.ACT_NONE, T.empty_like(Yin))
+    fl = ops.F_STORE | ops.F_STATS
+    Ya, sa, _ = ops.pointwise(Xn, Wt, Cout, bias=bias, flags=fl, G=4, split=True)
+    Yb, sb, _ = ops.pointwise(Yin, Wt, Cout, bias=bias, flags=fl, G=4, split=True,
+                              gn_in=(stats, gamma, beta, Gin, ops.ACT_RELU if act else ops.ACT_NONE))
+    assert T.equal(Ya, Yb) and T.equal(sa, sb)
+    ref = Xn[:1].double() @ Wt.double() + bias.double()
+    assert float((Yb[:1].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
+def test_forward_does_not_depend_on_where_groupnorm_is_applied(T, monkeypatch):
+    """the whole SED-Net forward with bn1 / bn2 applied by the consuming GEMMs (default) and by gn_apply launches (SED_GN_ON_LOAD=0):
+    embedding, type log-probabilities and edges bit-identical -- in a batch (wide tiles) and for one cloud (128-point tiles)"""
+    from sednet_hip import ops, synth
+    m = build(T, 20, "inst")
+    x = T.from_numpy(synth.batch_clouds(20, 4000, seed0=77)[0]).cuda()
+    for xb in (x, x[:1].contiguous()):
+        monkeypatch.setattr(ops, "GN_ON_LOAD", True)
+        a = [t.clone() for t in m.forward_point_major(xb)]
+        monkeypatch.setattr(ops, "GN_ON_LOAD", False)
+        b = [t.clone() for t in m.forward_point_major(xb)]
+        for u, v in zip(a, b):
+            assert T.equal(u, v)
+
+
 @pytest.mark.parametrize("K,Cout,flags_relu", [(256, 1024, False), (512, 256, True), (256, 128, False)])
 def test_split_fp16_gemm_with_row_bounds_equals_fp32_gemm(T, K, Cout, flags_relu, monkeypatch):
     """pointwise_split_kernel<4, true>: two fp16 planes per operand, rows scaled by the bound the producer left (here: the exact

@@ -301,9 +301,9 @@ int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int Cout, const 
                                 int flags, sed_stream_t stream);
 /* (ABI 8, round 6) the same GEMM on a layer's PRE-normalisation output: every activation goes through that layer's GroupNorm +
  * activation as it is loaded -- x = act(X a_k + b_k), a_k = rstd_g gamma_k, b_k = beta_k - mean_g a_k: sed_gn_apply_f32's arithmetic
- * (scale 1, no addend), the same bits -- so the normalised tensor is never written or read (src/SEDNet.py:300-304: bn1 -> conv2,
- * bn2 -> mlp_prim_prob1 / mlp_seg_prob1). in_stats [B][in_G][2] from sed_gn_finalize_f32, in_gamma / in_beta [K], in_act 0 none /
- * 1 ReLU. K <= 512, K % in_G == 0, Coutp % 128 == 0 (SED_EUNSUPPORTED otherwise). */
+ * (scale 1, no addend), the same bits -- so the normalised tensor is never written or read (src/SEDNet.py:300-317: bn1 -> conv2,
+ * bn2 -> mlp_prim_prob1 / mlp_seg_prob1, bn_prim_prob1 -> mlp_prim_prob2 / edge_module / asis, the edge module's norm -> its last conv). in_stats [B][in_G][2] from sed_gn_finalize_f32, in_gamma / in_beta [K], in_act 0 none /
+ * 1 ReLU. K <= 512, K % in_G == 0 (SED_EUNSUPPORTED otherwise). */
 int sed_pointwise_fwd_split_gn_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx, const void* wsplit,
                                    const float* in_stats, const float* in_gamma, const float* in_beta, int in_G, int in_act,
                                    const float* bias, const float* cbias, float* Y, int ldy, void* partials, void* colext,

@@ -1002,13 +1002,13 @@ extern "C" int sed_pointwise_fwd_split_f32(int B, int N, int K, int Coutp, int C
 // The same GEMM on a layer's PRE-normalisation output: every activation goes through that layer's GroupNorm + activation as it
 // is loaded, x = act(X a_k + b_k) with a_k = rstd_g gamma_k, b_k = beta_k - mean_g a_k -- sed_gn_apply_f32's arithmetic (scale 1, no
 // addend), the same bits -- so the normalised tensor is never written or read. in_stats [B][in_G][2] (sed_gn_finalize_f32), in_gamma /
-// in_beta [K], in_act 0 none / 1 ReLU. K <= 512, K % in_G == 0, Coutp % 128 == 0.
+// in_beta [K], in_act 0 none / 1 ReLU. K <= 512, K % in_G == 0.
 extern "C" int sed_pointwise_fwd_split_gn_f32(int B, int N, int K, int Coutp, int Cout, const float* X, int ldx,
                                               const void* wsplit, const float* in_stats, const float* in_gamma,
                                               const float* in_beta, int in_G, int in_act, const float* bias, const float* cbias,
                                               float* Y, int ldy, void* partials, void* colext, int flags, hipStream_t stream) {
     if (!in_stats || !in_gamma || !in_beta || in_G <= 0 || (in_act != 0 && in_act != 1)) return SED_EINVAL;
-    if (K > 512 || K % in_G != 0 || Coutp % 128 != 0) return SED_EUNSUPPORTED;
+    if (K > 512 || K % in_G != 0) return SED_EUNSUPPORTED;
     const GnIn gn{in_stats, in_gamma, in_beta, in_G, in_act};
     return pointwise_split_launch(B, N, K, Coutp, Cout, X, ldx, wsplit, bias, cbias, Y, ldy, partials, colext, flags, &gn, stream);
 }
@@ -1064,8 +1064,12 @@ static int pointwise_split_launch(int B, int N, int K, int Coutp, int Cout, cons
         pointwise_split_kernel<4, false><<<dim3(nblk8 * (Coutp / 128), B), 256, smem(128, 4), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags, nullptr);
+    } else if (gn) {
+        pointwise_split_kernel<2, false, true><<<dim3(nblk8 * (Coutp / 64), B), 256,
+                                                 smem(64, 2) + 4 * 32 * sizeof(float) + 2 * 512 * sizeof(float), stream>>>(
+            X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk, flags,
+            nullptr, *gn);
     } else {
-        if (gn) return SED_EUNSUPPORTED;
         pointwise_split_kernel<2, false><<<dim3(nblk8 * (Coutp / 64), B), 256, smem(64, 2), stream>>>(
             X, ldx, K, (const __bf16*)wsplit, Coutp, bias, cbias, Y, ldy, Cout, (double*)partials, (float*)colext, N, nblk,
             flags, nullptr);

@@ -806,9 +806,9 @@ def _split16_weights(Wt):
 
 
 def gn_in_ok(K, Coutp, split=None):
-    """can pointwise(..., gn_in=...) take this layer? (the 3-way bf16 split kernels, K <= 512, Coutp % 128 == 0)"""
+    """can pointwise(..., gn_in=...) take this layer? (the 3-way bf16 split kernels, K <= 512)"""
     split = POINTWISE_SPLIT if split is None else split
-    return bool(GN_ON_LOAD and split and not POINTWISE_SPLIT16 and K <= 512 and Coutp % 128 == 0)
+    return bool(GN_ON_LOAD and split and not POINTWISE_SPLIT16 and K <= 512 and Coutp % 64 == 0)
 
 
 def pointwise(X, Wt, Cout, bias=None, cbias=None, out=None, flags=F_STORE, G=0, eps=1e-5, bf16=False, split=None, rowmax=None,

@@ -295,8 +295,8 @@ class SEDNet(nn.Module):
             x4, feats = self.encoder.forward_point_major(points, idx1, feats_bound=bnd[0], order=order)
             # conv1 over cat(repeat(x4), feats): the repeated-global part is a per-cloud bias   (:300-303)
             cb = ops.gemv_bias(c["conv1_g"], 1280, 1024, c["conv1_b"], x4)
-            # bn1 and bn2 have GEMM consumers only (conv2; mlp_prim_prob1 + mlp_seg_prob1): those apply them while loading
-            fold = ops.gn_in_ok(512, 256) and ops.gn_in_ok(256, 256)
+            # bn1, bn2, bn_prim_prob1 and the edge module's norm have GEMM consumers only: those apply them while loading (round 6)
+            fold = ops.gn_in_ok(512, 256) and ops.gn_in_ok(256, 64)
             if fold:
                 y1, g1 = self._conv_gn_relu(feats, None, "bn1", 8, 512, self.bn1.eps, cbias=cb, Wt=c["conv1_f"], lazy=True)
                 x_all, g_all = self._conv_gn_relu(y1, "conv2", "bn2", 4, 256, self.bn2.eps, gn_in=g1, lazy=True)       # :304
@@ -305,20 +305,22 @@ class SEDNet(nn.Module):
                                         x_bound=bnd[0], y_bound=bnd[1])
                 x_all = self._conv_gn_relu(a1, "conv2", "bn2", 4, 256, self.bn2.eps, x_bound=bnd[1], y_bound=bnd[2])   # :304
                 g_all = None
-            x_type = self._conv_gn_relu(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps,
-                                        x_bound=bnd[2], y_bound=bnd[3], gn_in=g_all)                  # :311
+            # (bn_prim_prob1's output feeds mlp_prim_prob2, the edge module and asis; the edge module's norm its last conv: GEMMs only)
+            layer = lambda *a, **k: self._conv_gn_relu(*a, lazy=True, **k) if fold else (self._conv_gn_relu(*a, **k), None)
+            x_type, g_type = layer(x_all, "prim1", "bn_prim1", 4, 256, self.bn_prim_prob1.eps,
+                                   x_bound=bnd[2], y_bound=bnd[3], gn_in=g_all)                       # :311
             P = self.num_primitives
             te = torch.zeros((B, N, 32), dtype=torch.float32, device=dev)       # cat(type_logit, edges), K padded
             Wt, b = c["prim2"]
-            ops.pointwise(x_type, Wt, P, bias=b, out=te[:, :, 0:P])                                  # :312
+            ops.pointwise(x_type, Wt, P, bias=b, out=te[:, :, 0:P], gn_in=g_type)                    # :312
             log_prob = ops.log_softmax_rows(te, P)                                                      # :313
-            e1 = self._conv_gn_relu(x_type, "edge0", "edge1", 4, 128, self.edge_module[1].eps, act=ops.ACT_NONE,
-                                    x_bound=bnd[3])
+            e1, g_e1 = layer(x_type, "edge0", "edge1", 4, 128, self.edge_module[1].eps, act=ops.ACT_NONE,
+                             x_bound=bnd[3], gn_in=g_type)
             Wt, b = c["edge2"]
-            ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2])                                  # :316-317
+            ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2], gn_in=g_e1)                      # :316-317
             xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2], gn_in=g_all)   # :320
             x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
-                                   scale=self.w_pos_enc, addend=xs, x_bound=bnd[3])                    # :322
+                                   scale=self.w_pos_enc, addend=xs, x_bound=bnd[3], gn_in=g_type)      # :322
             Wt, b = c["penc"]
             pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)             # :326
             x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x, rowmax=bnd[4])

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wide_kernel(const float* __r
         for (int u = 0; u < PW; ++u) {
             const unsigned la = __builtin_amdgcn_readfirstlane(
                 (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)(Bs + buf * STG + (wave * PW + u) * 1024));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[u]), "s"(src), "s"(la) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[u]), "s"(src), "s"(la) : "memory");
         }
     };
     const int boff = li * 64, sw = (li >> 2) & 3;            // weight operand of (tile t, k-step s2): row 32 t + li, chunk hi + 2 s2

@@ -222,7 +222,7 @@ def test_default_flow_mean_seg_iou_over_the_bench_set(T, golden, capsys):
     through the reference's dense route (torch.lobpcg with a random start, torch.manual_seed(11) per cloud) plus two more torch seeds on the
     first 16 clouds (make_64_hpnet.py). torch.lobpcg's start is random, so the reference's own mean moves from seed to seed; the contract's
     "within 1e-3" is therefore held to the reference's own seed-to-seed spread of the MEAN: per-cloud seed variance from the 3 x 16 runs ->
-    sigma of a 64-cloud mean; the device's mean over three of its own seeds must lie within three standard errors of the difference
+    sigma of a 64-cloud mean; the device's mean over three of its own seeds must lie within two standard errors of the difference
     (or 1e-3, whichever is larger). Bandwidths, cluster counts and label agreement are held to the same spread."""
     import torch
     from conftest import label_agreement
@@ -259,7 +259,9 @@ def test_default_flow_mean_seg_iou_over_the_bench_set(T, golden, capsys):
     var_c = r3["seg_iou"].var(axis=1, ddof=1)                                   # per cloud
     sigma_mean = float(np.sqrt(var_c.mean() / 64))                              # of a 64-cloud mean under one seed per cloud
     d_mean = float(dev_iou.mean() - ref_iou.mean())
-    tol = max(1e-3, 3.0 * sigma_mean * np.sqrt(1.0 + 1.0 / len(dev_seeds)))
+    # (round 6: two standard errors, not three -- VERDICT r5: three would also pass a 1.5e-2 regression; the device's three seeds are
+    #  bit-reproducible, so the tighter bound cannot flake)
+    tol = max(1e-3, 2.0 * sigma_mean * np.sqrt(1.0 + 1.0 / len(dev_seeds)))
     ref_means16 = r3["seg_iou"].mean(axis=0)                                    # the reference's own 16-cloud means per seed
     # label agreement: device vs reference (seed 11) on all clouds against reference vs reference on the 16 x 3 pairs
     rr = [label_agreement(g[f"s{s}_t{a}_labels"], g[f"s{s}_t{b_}_labels"])["rate"] for s in seeds[:n16]
@@ -269,7 +271,7 @@ def test_default_flow_mean_seg_iou_over_the_bench_set(T, golden, capsys):
         "# The reference's DEFAULT flow (HPNet on) over the 64 bench clouds (tests/test_gpu_hpnet.py, tests/golden/f_64_hpnet.npz)", "",
         f"* mean seg-IoU over the 64 clouds: reference (torch seed {main}) {ref_iou.mean():.6f}; device, seeds {dev_seeds}: "
         f"{', '.join(f'{v:.6f}' for v in dev_iou.mean(1))} (mean {dev_iou.mean():.6f}); **delta {d_mean:+.2e}**, allowed {tol:.2e} "
-        f"(3 standard errors; sigma of a 64-cloud mean from the reference's own seed-to-seed variance: {sigma_mean:.2e})",
+        f"(2 standard errors; sigma of a 64-cloud mean from the reference's own seed-to-seed variance: {sigma_mean:.2e})",
         f"* the reference's own 16-cloud means for its three seeds: {', '.join(f'{v:.6f}' for v in ref_means16)} (range "
         f"{ref_means16.max() - ref_means16.min():.2e}); the device's on the same 16 clouds: {', '.join(f'{v:.6f}' for v in dev_iou[:, :n16].mean(1))}",
         f"* per-cloud seg-IoU seed-to-seed standard deviation of the reference (16 clouds): median {np.median(np.sqrt(var_c)):.2e}, max {np.sqrt(var_c).max():.2e}",
@@ -283,7 +285,7 @@ def test_default_flow_mean_seg_iou_over_the_bench_set(T, golden, capsys):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "r05_hpnet_64_vs_reference.md"), "w") as f:
+    with open(os.path.join(root, "gpurun_out", "r06_hpnet_64_vs_reference.md"), "w") as f:
         f.write("\n".join(rep) + "\n")
     with capsys.disabled():
         print("\n" + "\n".join(rep[2:]))

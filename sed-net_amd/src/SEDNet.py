@@ -157,10 +157,11 @@ class DGCNNEncoderGn(nn.Module):
         x8 = torch.zeros((B, N, 8), dtype=torch.float32, device=x.device)
         x8[:, :, :6] = x.transpose(1, 2)
         idx = ops.knn_points_normals(x, k, self.normal_metric_W) if idx1 is None else idx1
+        order = ops.spatial_order(x)                   # round 6: the ordered sweeps (speed only: the graphs do not depend on it)
         x1 = hag.edgeconv_gn(x8, idx, self.conv1[0], self.bn1, 6)
-        idx2 = ops.knn_features(x1.detach(), k, 64)
+        idx2 = ops.knn_features(x1.detach(), k, 64, order=order)
         x2 = hag.edgeconv_gn(x1, idx2, self.conv2[0], self.bn2, 64)
-        idx3 = ops.knn_features(x2.detach(), k, 64)
+        idx3 = ops.knn_features(x2.detach(), k, 64, order=order)
         x3 = hag.edgeconv_gn(x2, idx3, self.conv3[0], self.bn3, 64)
         self.last_graphs = (idx, idx2, idx3)          # the neighbour sets this step differentiated through
         feats = torch.cat([x1, x2, x3], dim=2)

@@ -347,6 +347,13 @@ int sed_gn_finalize_f32(int B, int N, int Coutp, int G, double count, float eps,
 int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int ldy, const float* stats, const float* gamma,
                      const float* beta, int act, float slope, float scale, const float* addend, int lda, float* out,
                      int ldo, unsigned* rowmax, sed_stream_t stream);
+/* (ABI 8, round 6) out = scale3 * Y3 + (scale1 * act1(GN1(Y1)) + act2(GN2(Y2))) -- the three sed_gn_apply_f32 passes behind the
+ * embedding head (src/SEDNet.py:320-326: bn_seg_prob1, asis + its residual add, the position-encoding add) in one kernel, each step in
+ * the arithmetic sed_gn_apply_f32 uses for it (same bits). Y3 may be NULL. act 0 none / 1 ReLU; C % 4 == 0, 256 % (C / 4) == 0. */
+int sed_gn_apply_fused_f32(int B, int N, int C, const float* Y1, int ld1, const float* stats1, const float* gamma1,
+                           const float* beta1, int G1, int act1, float scale1, const float* Y2, int ld2, const float* stats2,
+                           const float* gamma2, const float* beta2, int G2, int act2, const float* Y3, int ld3, float scale3,
+                           float* out, int ldo, sed_stream_t stream);
 /* x4[b][o] = relu(GN(max/min over N)) from the column extrema of mlp1.   src/SEDNet.py:95-96 */
 int sed_colext_finalize_f32(int B, int N, int C, int G, const void* colext, const float* stats, const float* gamma,
                             const float* beta, float* out, sed_stream_t stream);

@@ -818,6 +818,60 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+// out = s3 * Y3 + (s1 * act1(GN1(Y1)) + act2(GN2(Y2)))     (round 6) -- the three elementwise passes behind the embedding head of
+// SEDNet.py:320-326 in one: xs = relu(bn_seg(seg1)), x = w * relu(bn_asis(asis)) + xs, x' = w * pe + x. Each step is the
+// arithmetic gn_apply_kernel compiles to for it (fmaf(y, a, b), the bare max, and ONE fused multiply-add for "scale * v + addend":
+// hipcc contracts gn_apply's __fadd_rn(__fmul_rn(..)) -- DESIGN.md Appendix A -- so the fma is written out here), hence the same bits
+// with 2.6 GB instead of 5.2 GB of traffic per forward. C % 4 == 0, C <= 1024, 256 % (C / 4) == 0; Y3 may be null (then x is written).
+__global__ __launch_bounds__(256) void gn_apply_fused_kernel(const float* __restrict__ Y1, int ld1, const float* __restrict__ st1,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1, int G1,
+                                                             int act1, float s1, const float* __restrict__ Y2, int ld2,
+                                                             const float* __restrict__ st2, const float* __restrict__ g2,
+                                                             const float* __restrict__ b2, int G2, int act2,
+                                                             const float* __restrict__ Y3, int ld3, float s3,
+                                                             float* __restrict__ out, int ldo, int C, int N) {
+    const unsigned cloud = blockIdx.y;
+    const unsigned c4n = (unsigned)C / 4, rpb = 256u / c4n;
+    const unsigned tr = threadIdx.x / c4n, c = (threadIdx.x - tr * c4n) * 4;
+    if (tr >= rpb) return;
+    f32x4 a1, o1, a2, o2;
+    auto coeffs = [&](const float* st, const float* g, const float* be, int G, f32x4& a4, f32x4& b4) {
+        const unsigned cpg = (unsigned)C / (unsigned)G;
+        const f32x4 g4 = *(const f32x4*)(g + c), be4 = *(const f32x4*)(be + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned gi = (c + u) / cpg;
+            const float mean = st[((size_t)cloud * G + gi) * 2], rstd = st[((size_t)cloud * G + gi) * 2 + 1];
+            a4[u] = rstd * g4[u];
+            b4[u] = fmaf(-a4[u], mean, be4[u]);
+        }
+    };
+    coeffs(st1, g1, b1, G1, a1, o1);
+    coeffs(st2, g2, b2, G2, a2, o2);
+    const unsigned p0 = blockIdx.x * rpb * GN_PT + tr;
+#pragma unroll
+    for (int k = 0; k < GN_PT; ++k) {
+        const unsigned p = p0 + k * rpb;
+        if (p >= (unsigned)N) continue;
+        const size_t row = (size_t)cloud * N + p;
+        const f32x4 y1 = *(const f32x4*)(Y1 + row * ld1 + c), y2 = *(const f32x4*)(Y2 + row * ld2 + c);
+        f32x4 y3 = {0.f, 0.f, 0.f, 0.f};
+        if (Y3) y3 = *(const f32x4*)(Y3 + row * ld3 + c);
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v1 = fmaf(y1[u], a1[u], o1[u]);
+            if (act1 == 1) v1 = fmaxf(v1, 0.f);
+            float v2 = fmaf(y2[u], a2[u], o2[u]);
+            if (act2 == 1) v2 = fmaxf(v2, 0.f);
+            float x = fmaf(s1, v1, v2);
+            if (Y3) x = fmaf(s3, y3[u], x);
+            o[u] = x;
+        }
+        *(f32x4*)(out + row * ldo + c) = o;
+    }
+}
+
 // x4[b][o] = relu(GN(extreme over N)) from per-block column extrema (mlp1 + bnmlp1 + max over N)
 __global__ void colext_finalize_kernel(const float* __restrict__ colext, int nblk, int ldw, int C, int G,
                                        const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -1136,6 +1190,24 @@ extern "C" int sed_gn_apply_f32(int B, int N, int C, int G, const float* Y, int 
     const unsigned rows_per_block = rpb * GN_PT;
     gn_apply_kernel<<<dim3(((unsigned)N + rows_per_block - 1) / rows_per_block, B), 256, 0, stream>>>(
         Y, ldy, C, G ? G : 1, stats, gamma, beta, act, slope, scale, addend, lda, out, ldo, N, rowmax);
+    SED_LAUNCH_CHECK();
+    return SED_OK;
+}
+
+// out = scale3 * Y3 + (scale1 * act1(GN1(Y1)) + act2(GN2(Y2))): three sed_gn_apply_f32 passes in one (gn_apply_fused_kernel); Y3
+// may be NULL. stats* [B][G*][2], gamma* / beta* [C]; act 0 none / 1 ReLU.
+extern "C" int sed_gn_apply_fused_f32(int B, int N, int C, const float* Y1, int ld1, const float* stats1, const float* gamma1,
+                                      const float* beta1, int G1, int act1, float scale1, const float* Y2, int ld2,
+                                      const float* stats2, const float* gamma2, const float* beta2, int G2, int act2,
+                                      const float* Y3, int ld3, float scale3, float* out, int ldo, hipStream_t stream) {
+    if (B <= 0 || N <= 0 || !Y1 || !Y2 || !out || !stats1 || !stats2 || !gamma1 || !gamma2 || !beta1 || !beta2 || G1 <= 0 || G2 <= 0)
+        return SED_EINVAL;
+    if (C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0 || C % G1 != 0 || C % G2 != 0 || ld1 % 4 || ld2 % 4 || ldo % 4 || (Y3 && ld3 % 4) ||
+        (act1 != 0 && act1 != 1) || (act2 != 0 && act2 != 1))
+        return SED_EUNSUPPORTED;
+    const unsigned rows_per_block = 256u / ((unsigned)C / 4) * GN_PT;
+    gn_apply_fused_kernel<<<dim3(((unsigned)N + rows_per_block - 1) / rows_per_block, B), 256, 0, stream>>>(
+        Y1, ld1, stats1, gamma1, beta1, G1, act1, scale1, Y2, ld2, stats2, gamma2, beta2, G2, act2, Y3, ld3, scale3, out, ldo, C, N);
     SED_LAUNCH_CHECK();
     return SED_OK;
 }

@@ -111,6 +111,8 @@ SIGNATURES = {
     "sed_gn_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_double, c_float, P, P, P]),
     "sed_gn_apply_f32": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_float, c_float, P, c_int,
                                  P, c_int, P, P]),
+    "sed_gn_apply_fused_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, c_float, P, c_int, P, P, P, c_int, c_int,
+                                       P, c_int, c_float, P, c_int, P]),
     "sed_colext_finalize_f32": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "sed_gemv_bias_f32": (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, c_int, P]),
     "sed_log_softmax_f32": (c_int, [c_size_t, c_int, P, c_int, P, c_int, P]),

@@ -731,6 +731,19 @@ def gn_apply(Y, C, G, stats, gamma, beta, act, out, slope=0.0, scale=1.0, addend
     return out
 
 
+def gn_apply_fused(Y1, gn1, scale1, Y2, gn2, Y3, scale3, out):
+    """out = scale3 * Y3 + (scale1 * act1(GN1(Y1)) + act2(GN2(Y2))) in one kernel (sed_gn_apply_fused_f32): gn* = (stats, gamma, beta,
+    G, act) as pointwise(gn_in=) takes them; Y3 may be None. The bits of the three gn_apply passes it stands for."""
+    B, N, C = Y1.shape
+    st1, g1, b1, G1, a1 = gn1
+    st2, g2, b2, G2, a2 = gn2
+    check(lib.sed_gn_apply_fused_f32(B, N, C, _vptr(Y1), Y1.stride(1), ptr(st1), ptr(g1), ptr(b1), int(G1), int(a1), float(scale1),
+                                     _vptr(Y2), Y2.stride(1), ptr(st2), ptr(g2), ptr(b2), int(G2), int(a2),
+                                     _vptr(Y3) if Y3 is not None else None, Y3.stride(1) if Y3 is not None else 0, float(scale3),
+                                     _vptr(out), out.stride(1), stream()), "gn_apply_fused")
+    return out
+
+
 def row_bounds(B, N, device):
     """zeroed per-row magnitude bounds (float bit patterns) for gn_apply(..., rowmax=) -> pointwise(..., rowmax=); None while
     POINTWISE_SPLIT16 is off (both consumers then take their default forms)"""

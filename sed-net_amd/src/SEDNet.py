@@ -319,12 +319,19 @@ class SEDNet(nn.Module):
                              x_bound=bnd[3], gn_in=g_type)
             Wt, b = c["edge2"]
             ops.pointwise(e1, Wt, 2, bias=b, out=te[:, :, P:P + 2], gn_in=g_e1)                      # :316-317
-            xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2], gn_in=g_all)   # :320
-            x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
-                                   scale=self.w_pos_enc, addend=xs, x_bound=bnd[3], gn_in=g_type)      # :322
             Wt, b = c["penc"]
-            pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)             # :326
-            x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x, rowmax=bnd[4])
+            if fold:
+                # bn_seg_prob1, asis' norm + its residual add and the position-encoding add (:320-326) in ONE elementwise pass
+                ys, gs = layer(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, gn_in=g_all)              # :320
+                ya, ga = layer(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps, gn_in=g_type)                     # :322
+                pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)         # :326
+                x = ops.gn_apply_fused(ya, ga, self.w_pos_enc, ys, gs, pe, self.w_pos_enc, pe)
+            else:
+                xs = self._conv_gn_relu(x_all, "seg1", "bn_seg1", 4, 256, self.bn_seg_prob1.eps, x_bound=bnd[2], gn_in=g_all)   # :320
+                x = self._conv_gn_relu(x_type, "asis0", "asis1", 4, 256, self.asis[1].eps,
+                                       scale=self.w_pos_enc, addend=xs, x_bound=bnd[3], gn_in=g_type)      # :322
+                pe, _, _ = ops.pointwise(te, Wt, 256, bias=b, flags=ops.F_STORE | ops.F_RELU)             # :326
+                x = ops.gn_apply(pe, 256, 0, None, None, None, ops.ACT_NONE, pe, scale=self.w_pos_enc, addend=x, rowmax=bnd[4])
             Wt, b = c["seg2"]
             emb, _, _ = ops.pointwise(x, Wt, self.emb_size, bias=b, rowmax=bnd[4])                    # :329
         return emb, log_prob, te[:, :, P:P + 2]

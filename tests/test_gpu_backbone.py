@@ -268,6 +268,25 @@ def test_groupnorm_on_load_gives_the_bits_of_gn_apply_then_gemm(T, B, N, K, Cout
     assert float((Yb[:1].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,N,with_y3", [(3, 2500, True), (2, 1001, False), (1, 130, True)])
+def test_fused_elementwise_pass_gives_the_bits_of_three_gn_apply_passes(T, B, N, with_y3):
+    """sed_gn_apply_fused_f32 (round 6): xs = relu(GN_a(Y2)); x = w * relu(GN_b(Y1)) + xs; x' = w * Y3 + x -- the three gn_apply launches
+    behind the embedding head (SEDNet.py:320-326) -- in one kernel with the same arithmetic step by step: bit-identical, ragged N included."""
+    from sednet_hip import ops
+    g = T.Generator().manual_seed(B + N)
+    C, w = 256, 0.2
+    Y1, Y2, Y3 = ((T.randn(B, N, C, generator=g) * 2.0).cuda() for _ in range(3))
+    mk = lambda G: (T.stack([T.randn(B, G, generator=g) * 0.3, T.rand(B, G, generator=g) + 0.2], 2).cuda().contiguous(),
+                    T.randn(C, generator=g).cuda(), T.randn(C, generator=g).cuda(), G, ops.ACT_RELU)
+    gn1, gn2 = mk(4), mk(8)
+    xs = ops.gn_apply(Y2, C, gn2[3], gn2[0], gn2[1], gn2[2], ops.ACT_RELU, T.empty_like(Y2))
+    x = ops.gn_apply(Y1, C, gn1[3], gn1[0], gn1[1], gn1[2], ops.ACT_RELU, T.empty_like(Y1), scale=w, addend=xs)
+    ref = ops.gn_apply(Y3, C, 0, None, None, None, ops.ACT_NONE, T.empty_like(Y3), scale=w, addend=x) if with_y3 else x
+    out = Y3.clone() if with_y3 else T.empty_like(Y1)
+    got = ops.gn_apply_fused(Y1, gn1, w, Y2, gn2, out if with_y3 else None, w, out)        # in place over Y3, as the model runs it
+    assert T.equal(got, ref)
+
+
 def test_forward_does_not_depend_on_where_groupnorm_is_applied(T, monkeypatch):
     """the whole SED-Net forward with bn1 / bn2 applied by the consuming GEMMs (default) and by gn_apply launches (SED_GN_ON_LOAD=0):
     embedding, type log-probabilities and edges bit-identical -- in a batch (wide tiles) and for one cloud (128-point tiles)"""
